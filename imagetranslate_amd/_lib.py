@@ -1,0 +1,112 @@
+"""ctypes binding of the C-ABI library ``libimt_hip.so`` (declared in ``include/imt_hip.h``).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be bound this module
+raises at import-of-use time.  PyTorch is used by callers only for device memory and streams; no torch type
+crosses the boundary (plain pointers and sizes only).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimt_hip.so")
+
+IMT_F32, IMT_BF16 = 0, 1
+IMT_NT, IMT_NN, IMT_TN = 0, 1, 2
+IMT_AUX_NONE, IMT_AUX_GELU_FWD, IMT_AUX_DGELU = 0, 1, 2
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("dtype", c_int32), ("layout", c_int32),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("A", c_void_p), ("lda", c_int64),
+        ("B", c_void_p), ("ldb", c_int64),
+        ("C", c_void_p), ("ldc", c_int64),
+        ("c_dtype", c_int32), ("accumulate", c_int32),
+        ("bias", c_void_p),
+        ("resid", c_void_p), ("ldr", c_int64),
+        ("aux", c_void_p), ("ldaux", c_int64),
+        ("aux_mode", c_int32), ("split_k", c_int32),
+        ("alpha", c_float), ("dropout_p", c_float),
+        ("dropout_seed", c_uint64),
+    ]
+
+
+class AttnArgs(Structure):
+    _fields_ = [
+        ("dtype", c_int32),
+        ("B", c_int32), ("H", c_int32), ("Tq", c_int32), ("Tk", c_int32), ("head_dim", c_int32),
+        ("Q", c_void_p), ("ldq", c_int64),
+        ("K", c_void_p), ("ldk", c_int64),
+        ("V", c_void_p), ("ldv", c_int64),
+        ("O", c_void_p), ("ldo", c_int64),
+        ("lse", c_void_p),
+        ("key_mask", c_void_p), ("query_mask", c_void_p), ("mask3d", c_void_p),
+        ("causal", c_int32), ("scale", c_float), ("dropout_p", c_float),
+        ("dropout_seed", c_uint64),
+        ("dO", c_void_p), ("lddo", c_int64),
+        ("dQ", c_void_p), ("lddq", c_int64),
+        ("dK", c_void_p), ("lddk", c_int64),
+        ("dV", c_void_p), ("lddv", c_int64),
+        ("delta", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/imt_hip.h declares (tests/test_cabi.py checks)
+_P = c_void_p
+SIGNATURES = {
+    "imt_version": (c_int, []),
+    "imt_last_error": (c_char_p, []),
+    "imt_gemm": (c_int, [POINTER(GemmArgs), _P]),
+    "imt_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, _P]),
+    "imt_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, _P]),
+    "imt_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, c_float,
+                                  c_uint64, _P]),
+    "imt_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "imt_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P]),
+    "imt_attention_fwd": (c_int, [POINTER(AttnArgs), _P]),
+    "imt_attention_bwd": (c_int, [POINTER(AttnArgs), _P]),
+    "imt_gather_rows": (c_int, [c_int, _P, c_int64, _P, _P, c_int64, c_int, c_int, _P]),
+    "imt_scatter_rows": (c_int, [c_int, _P, c_int64, _P, _P, c_int64, c_int, c_int, _P]),
+    "imt_log_softmax_fwd": (c_int, [c_int, _P, c_int64, _P, c_int64, _P, c_int, c_int, _P]),
+    "imt_log_softmax_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, c_int64, c_int, c_int, _P]),
+    "imt_smoothed_nll_fwd": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_float, c_int64, _P]),
+    "imt_smoothed_nll_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_int64, _P]),
+    "imt_xent_fused_fwd_bwd": (c_int, [c_int, _P, c_int64, _P, _P, c_int, c_int, c_float, c_int64, c_float, _P]),
+    "imt_sumsq": (c_int, [_P, c_int64, _P, _P]),
+    "imt_clip_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_float,
+                              c_int64, c_int, _P]),
+    "imt_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
+    "imt_gated_mix": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, _P]),
+}
+
+_lib = None
+
+
+class ImtError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libimt_hip.so and bind every declared symbol.  Raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImtError(
+            "imagetranslate_amd: HIP extension %s is missing -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().imt_last_error()
+        raise ImtError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))

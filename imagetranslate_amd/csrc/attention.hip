@@ -1,0 +1,445 @@
+// Fused multi-head attention forward / backward (HF BertSelfAttention semantics):
+//   P = softmax(Q K^T * scale + (1 - mask) * -10000) ; [dropout] ; O = P V
+// Flash-style: the [Tq,Tk] score matrix never reaches HBM; forward saves one log-sum-exp per query row,
+// backward recomputes P from it.
+//
+// Layout of the work (wave64, 16x16 MFMA tiles, see mma.hpp):
+//   fwd / dQ  : one workgroup = 64 query rows of one (batch, head); each of its 4 waves owns 16 queries with
+//               the QUERY on the MFMA lane (S^T = K Q^T), so row max / row sum / rescale are lane-local plus
+//               two cross-lane shuffles, and the S^T accumulators are directly the B operand of
+//               O^T = V^T P^T (resp. dQ^T = K^T dS^T).  K/V tiles of 64 keys are staged in swizzled LDS;
+//               V (resp. K) is consumed through the transposed LDS read.
+//   dK/dV     : one workgroup = 64 keys; KEY on the lane (S = Q K^T), dV^T / dK^T accumulate in registers over
+//               all query tiles; Q and dO tiles are staged once and read both row-wise and transposed.
+// Nothing is summed across workgroups: no atomics, bitwise reproducible.
+#include "mma.hpp"
+
+namespace {
+
+struct AttnP {
+  int B, H, Tq, Tk;
+  const void* Q; int64_t ldq;
+  const void* K; int64_t ldk;
+  const void* V; int64_t ldv;
+  void* O; int64_t ldo;
+  float* lse;
+  const uint8_t* key_mask;
+  const uint8_t* query_mask;
+  const uint8_t* mask3d;
+  int causal;
+  float scale;
+  uint32_t drop_thresh; float inv_keep; uint64_t seed;
+  const void* dO; int64_t lddo;
+  void* dQ; int64_t lddq;
+  void* dK; int64_t lddk;
+  void* dV; int64_t lddv;
+  float* delta;
+};
+
+// stage a [64 rows][DH] tile (rows row0.. of one (b,h)) into swizzled LDS, zero-filling rows >= nrows
+template <typename T, int DH>
+IMT_DEVICE void stage_tile(char* tile, const T* base, int64_t ld, int row0, int nrows) {
+  constexpr int RB = DH * sizeof(T), CPR = RB / 16, EPC = 16 / sizeof(T);
+  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
+    const int tr = q / CPR, c = q % CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + tr < nrows) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + tr) * ld + c * EPC);
+    *reinterpret_cast<u32x4*>(tile + tile_off<RB>(tr, c)) = v;
+  }
+}
+
+// load NS register fragments of row (row0 + lane&15) straight from global (K-contiguous operand)
+template <typename T, int DH>
+IMT_DEVICE void load_row_frags(typename Frag<T>::type (&f)[DH * sizeof(T) / 64], const T* base, int64_t ld, int row0,
+                               int nrows) {
+  constexpr int NS = DH * sizeof(T) / 64, EPC = 16 / sizeof(T);
+  const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+  typedef typename Frag<T>::type frag_t;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + r < nrows) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + r) * ld + (4 * s + g) * EPC);
+    f[s] = __builtin_bit_cast(frag_t, v);
+  }
+}
+
+IMT_DEVICE bool mask_ok(const AttnP& p, int b, int i, int j, bool key_ok, bool query_ok) {
+  bool ok = key_ok && query_ok;
+  if (p.causal) ok = ok && (j <= i);
+  if (p.mask3d && i < p.Tq && j < p.Tk) ok = ok && (p.mask3d[((int64_t)b * p.Tq + i) * p.Tk + j] != 0);
+  return ok;
+}
+
+// accumulator tiles -> operand fragments of the following product (see mma.hpp, "permuted-K")
+template <typename T> struct AccOperand;
+template <> struct AccOperand<float> {
+  static constexpr int NFR = 4;  // one fragment per 16-row tile
+  static IMT_DEVICE f32x4 get(const f32x4 (&t)[4], int u) { return t[u]; }
+  template <int RB> static IMT_DEVICE f32x4 lds(const char* tile, int u, int col0) { return lds_frag_kperm_f32<RB>(tile, 16 * u, col0); }
+};
+template <> struct AccOperand<bf16_t> {
+  static constexpr int NFR = 2;  // one fragment per PAIR of 16-row tiles
+  static IMT_DEVICE bf16x8 get(const f32x4 (&t)[4], int u) { return acc_pair_to_frag(t[2 * u], t[2 * u + 1]); }
+  template <int RB> static IMT_DEVICE bf16x8 lds(const char* tile, int u, int col0) { return lds_frag_kperm_bf16<RB>(tile, 32 * u, col0); }
+};
+
+// =========================================================================================== forward
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * RB];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * RB];
+  __shared__ uint8_t kmask_s[64];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int i = q0 + r;  // this lane's query row
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
+
+  frag_t qf[NS];
+  load_row_frags<T, DH>(qf, Qb, p.ldq, q0, p.Tq);
+  const bool query_ok = (p.query_mask && i < p.Tq) ? (p.query_mask[(int64_t)b * p.Tq + i] != 0) : true;
+
+  f32x4 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (p.Tk + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    stage_tile<T, DH>(Ks, Kb, p.ldk, kt * 64, p.Tk);
+    stage_tile<T, DH>(Vs, Vb, p.ldv, kt * 64, p.Tk);
+    if (threadIdx.x < 64) {
+      const int j = kt * 64 + threadIdx.x;
+      kmask_s[threadIdx.x] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
+    }
+    __syncthreads();
+
+    // S^T tiles: rows <- keys (16 per tile), cols <- this wave's 16 queries
+    f32x4 s[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) mma16(s[nt], lds_frag_kcontig<T, RB>(Ks, 16 * nt, 4 * ks), qf[ks]);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int jl = 16 * nt + 4 * g + e, j = kt * 64 + jl;
+        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_s[jl] != 0, query_ok) ? 0.f : -10000.0f);
+        if (j >= p.Tk) v = -INFINITY;
+        s[nt][e] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pv = __expf(s[nt][e] - m_new);
+        psum += pv;
+        if (p.drop_thresh) {
+          const int j = kt * 64 + 16 * nt + 4 * g + e;
+          const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
+          pv = dropout_keep(p.seed, idx, p.drop_thresh) ? pv * p.inv_keep : 0.f;
+        }
+        s[nt][e] = pv;
+      }
+    l_run = l_run * alpha + psum;  // per-lane partial; lanes r, r+16, r+32, r+48 are combined at the end
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+    // O^T[d][m] += V^T[d][key] P^T[key][m]
+#pragma unroll
+    for (int u = 0; u < AccOperand<T>::NFR; ++u) {
+      const frag_t pf = AccOperand<T>::get(s, u);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) mma16(o[dt], AccOperand<T>::template lds<RB>(Vs, u, 16 * dt), pf);
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_run;
+  if (i < p.Tq) {
+    T* Ob = reinterpret_cast<T*>(p.O) + ((int64_t)b * p.Tq + i) * p.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(Ob + 16 * dt + 4 * g, o[dt] * inv_l);
+    if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Tq + i] = m_run + __logf(l_run);
+  }
+}
+
+// =========================================================================================== delta = rowsum(dO * O)
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+  // one thread per (b, i, h, 4-element group); DH/4 consecutive lanes reduce one head
+  constexpr int LPH = DH / 4;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.Tq * p.H * LPH;
+  float v = 0.f;
+  int64_t bi = 0; int h = 0;
+  if (gid < total) {
+    const int c = (int)(gid % LPH);
+    h = (int)((gid / LPH) % p.H);
+    bi = gid / ((int64_t)LPH * p.H);
+    const f32x4 a = Vec4<T>::load(reinterpret_cast<const T*>(p.dO) + bi * p.lddo + h * DH + 4 * c);
+    const f32x4 o = Vec4<T>::load(reinterpret_cast<const T*>(p.O) + bi * p.ldo + h * DH + 4 * c);
+    v = a[0] * o[0] + a[1] * o[1] + a[2] * o[2] + a[3] * o[3];
+  }
+#pragma unroll
+  for (int off = LPH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (gid < total && (gid % LPH) == 0) {
+    const int64_t bb = bi / p.Tq, ii = bi % p.Tq;
+    p.delta[(bb * p.H + h) * p.Tq + ii] = v;
+  }
+}
+
+// =========================================================================================== backward: dQ
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+  constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * RB];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * RB];
+  __shared__ uint8_t kmask_s[64];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int i = q0 + r;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)b * p.Tq * p.lddo + h * DH;
+
+  frag_t qf[NS], dof[NS];
+  load_row_frags<T, DH>(qf, Qb, p.ldq, q0, p.Tq);
+  load_row_frags<T, DH>(dof, dOb, p.lddo, q0, p.Tq);
+  const bool query_ok = (p.query_mask && i < p.Tq) ? (p.query_mask[(int64_t)b * p.Tq + i] != 0) : true;
+  const int64_t srow = ((int64_t)b * p.H + h) * p.Tq + (i < p.Tq ? i : 0);
+  const float lse_i = p.lse[srow], delta_i = p.delta[srow];
+
+  f32x4 dq[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (p.Tk + 63) / 64;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile<T, DH>(Ks, Kb, p.ldk, kt * 64, p.Tk);
+    stage_tile<T, DH>(Vs, Vb, p.ldv, kt * 64, p.Tk);
+    if (threadIdx.x < 64) {
+      const int j = kt * 64 + threadIdx.x;
+      kmask_s[threadIdx.x] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+        mma16(s[nt], lds_frag_kcontig<T, RB>(Ks, 16 * nt, 4 * ks), qf[ks]);
+        mma16(dp[nt], lds_frag_kcontig<T, RB>(Vs, 16 * nt, 4 * ks), dof[ks]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int jl = 16 * nt + 4 * g + e, j = kt * 64 + jl;
+        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_s[jl] != 0, query_ok) ? 0.f : -10000.0f);
+        float pv = (j < p.Tk) ? __expf(v - lse_i) : 0.f;
+        float dpv = dp[nt][e];
+        if (p.drop_thresh) {
+          const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
+          dpv = dropout_keep(p.seed, idx, p.drop_thresh) ? dpv * p.inv_keep : 0.f;
+        }
+        s[nt][e] = pv * (dpv - delta_i);  // dS^T
+      }
+#pragma unroll
+    for (int u = 0; u < AccOperand<T>::NFR; ++u) {
+      const frag_t dsf = AccOperand<T>::get(s, u);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) mma16(dq[dt], AccOperand<T>::template lds<RB>(Ks, u, 16 * dt), dsf);
+    }
+  }
+  if (i < p.Tq) {
+    T* dQb = reinterpret_cast<T*>(p.dQ) + ((int64_t)b * p.Tq + i) * p.lddq + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(dQb + 16 * dt + 4 * g, dq[dt] * p.scale);
+  }
+}
+
+// =========================================================================================== backward: dK, dV
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
+  constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char Qs[64 * RB];
+  __shared__ __attribute__((aligned(16))) char dOs[64 * RB];
+  __shared__ float lse_s[64], delta_s[64];
+  __shared__ uint8_t qmask_s[64];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int j = k0 + r;  // this lane's key
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)b * p.Tq * p.lddo + h * DH;
+
+  frag_t kf[NS], vf[NS];
+  load_row_frags<T, DH>(kf, Kb, p.ldk, k0, p.Tk);
+  load_row_frags<T, DH>(vf, Vb, p.ldv, k0, p.Tk);
+  const bool key_ok = (j < p.Tk) ? (p.key_mask ? (p.key_mask[(int64_t)b * p.Tk + j] != 0) : true) : false;
+
+  f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nqt = (p.Tq + 63) / 64;
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    stage_tile<T, DH>(Qs, Qb, p.ldq, qt * 64, p.Tq);
+    stage_tile<T, DH>(dOs, dOb, p.lddo, qt * 64, p.Tq);
+    if (threadIdx.x < 64) {
+      const int i = qt * 64 + threadIdx.x;
+      const int64_t srow = ((int64_t)b * p.H + h) * p.Tq + (i < p.Tq ? i : 0);
+      lse_s[threadIdx.x] = p.lse[srow];
+      delta_s[threadIdx.x] = p.delta[srow];
+      qmask_s[threadIdx.x] = (i < p.Tq) ? (p.query_mask ? p.query_mask[(int64_t)b * p.Tq + i] : (uint8_t)1) : (uint8_t)1;
+    }
+    __syncthreads();
+    // S tiles: rows <- queries (16 per tile), cols <- this wave's 16 keys
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      s[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+        mma16(s[mt], lds_frag_kcontig<T, RB>(Qs, 16 * mt, 4 * ks), kf[ks]);
+        mma16(dp[mt], lds_frag_kcontig<T, RB>(dOs, 16 * mt, 4 * ks), vf[ks]);
+      }
+    }
+    f32x4 pd[4];  // dropped P (operand of dV)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int il = 16 * mt + 4 * g + e, i = qt * 64 + il;
+        float v = s[mt][e] * p.scale + (mask_ok(p, b, i, j, key_ok, qmask_s[il] != 0) ? 0.f : -10000.0f);
+        float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_s[il]) : 0.f;
+        float dpv = dp[mt][e], pdv = pv;
+        if (p.drop_thresh) {
+          const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
+          const bool keep = dropout_keep(p.seed, idx, p.drop_thresh);
+          dpv = keep ? dpv * p.inv_keep : 0.f;
+          pdv = keep ? pv * p.inv_keep : 0.f;
+        }
+        pd[mt][e] = pdv;
+        s[mt][e] = pv * (dpv - delta_s[il]);  // dS
+      }
+#pragma unroll
+    for (int u = 0; u < AccOperand<T>::NFR; ++u) {
+      const frag_t pf = AccOperand<T>::get(pd, u);
+      const frag_t dsf = AccOperand<T>::get(s, u);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        mma16(dv[dt], AccOperand<T>::template lds<RB>(dOs, u, 16 * dt), pf);   // dV^T[d][n] += dO^T[d][m] P[m][n]
+        mma16(dk[dt], AccOperand<T>::template lds<RB>(Qs, u, 16 * dt), dsf);   // dK^T[d][n] += Q^T[d][m] dS[m][n]
+      }
+    }
+  }
+  if (j < p.Tk) {
+    T* dKb = reinterpret_cast<T*>(p.dK) + ((int64_t)b * p.Tk + j) * p.lddk + h * DH;
+    T* dVb = reinterpret_cast<T*>(p.dV) + ((int64_t)b * p.Tk + j) * p.lddv + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      Vec4<T>::store(dKb + 16 * dt + 4 * g, dk[dt] * p.scale);
+      Vec4<T>::store(dVb + 16 * dt + 4 * g, dv[dt]);
+    }
+  }
+}
+
+int check_args(const imt_attn_args* a, bool bwd) {
+  IMT_CHECK_ARG(a != nullptr, "attention: null args");
+  IMT_CHECK_ARG(a->dtype == IMT_F32 || a->dtype == IMT_BF16, "attention: bad dtype");
+  IMT_CHECK_ARG(a->head_dim == 32 || a->head_dim == 64, "attention: head_dim %d unsupported (32 or 64)", a->head_dim);
+  IMT_CHECK_ARG(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0, "attention: bad dims");
+  const int al = (a->dtype == IMT_BF16) ? 8 : 4;
+  IMT_CHECK_ARG(a->Q && a->K && a->V && a->O, "attention: null tensor");
+  IMT_CHECK_ARG(a->ldq % al == 0 && a->ldk % al == 0 && a->ldv % al == 0 && a->ldo % al == 0, "attention: ld must be 16-B multiples");
+  IMT_CHECK_ARG((((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O) & 15) == 0, "attention: 16-B alignment");
+  if (bwd) {
+    IMT_CHECK_ARG(a->dO && a->dQ && a->dK && a->dV && a->lse && a->delta, "attention_bwd: null tensor");
+    IMT_CHECK_ARG(a->lddo % al == 0 && a->lddq % al == 0 && a->lddk % al == 0 && a->lddv % al == 0, "attention_bwd: ld alignment");
+    IMT_CHECK_ARG((((uintptr_t)a->dO | (uintptr_t)a->dQ | (uintptr_t)a->dK | (uintptr_t)a->dV) & 15) == 0, "attention_bwd: 16-B alignment");
+  }
+  return IMT_OK;
+}
+
+AttnP make_params(const imt_attn_args* a) {
+  AttnP p;
+  p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
+  p.Q = a->Q; p.ldq = a->ldq; p.K = a->K; p.ldk = a->ldk; p.V = a->V; p.ldv = a->ldv; p.O = a->O; p.ldo = a->ldo;
+  p.lse = a->lse; p.key_mask = a->key_mask; p.query_mask = a->query_mask; p.mask3d = a->mask3d; p.causal = a->causal;
+  p.scale = a->scale;
+  p.drop_thresh = dropout_thresh(a->dropout_p);
+  p.inv_keep = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.seed = a->dropout_seed;
+  p.dO = a->dO; p.lddo = a->lddo; p.dQ = a->dQ; p.lddq = a->lddq; p.dK = a->dK; p.lddk = a->lddk; p.dV = a->dV; p.lddv = a->lddv;
+  p.delta = a->delta;
+  return p;
+}
+
+template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
+  dim3 grid(imt_cdiv(p.Tq, 64), p.H, p.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, st, p);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+template <typename T, int DH> int bwd_launch(const AttnP& p, hipStream_t st) {
+  const int64_t total = (int64_t)p.B * p.Tq * p.H * (DH / 4);
+  hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3(imt_cdiv(total, 256)), dim3(256), 0, st, p);
+  IMT_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64), p.H, p.B), dim3(256), 0, st, p);
+  IMT_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH>), dim3(imt_cdiv(p.Tk, 64), p.H, p.B), dim3(256), 0, st, p);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+}  // namespace
+
+extern "C" int imt_attention_fwd(const imt_attn_args* a, void* stream) {
+  int rc = check_args(a, false);
+  if (rc) return rc;
+  const AttnP p = make_params(a);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == IMT_F32) return a->head_dim == 32 ? fwd_launch<float, 32>(p, st) : fwd_launch<float, 64>(p, st);
+  return a->head_dim == 32 ? fwd_launch<bf16_t, 32>(p, st) : fwd_launch<bf16_t, 64>(p, st);
+}
+
+extern "C" int imt_attention_bwd(const imt_attn_args* a, void* stream) {
+  int rc = check_args(a, true);
+  if (rc) return rc;
+  const AttnP p = make_params(a);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == IMT_F32) return a->head_dim == 32 ? bwd_launch<float, 32>(p, st) : bwd_launch<float, 64>(p, st);
+  return a->head_dim == 32 ? bwd_launch<bf16_t, 32>(p, st) : bwd_launch<bf16_t, 64>(p, st);
+}

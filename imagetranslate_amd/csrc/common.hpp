@@ -1,0 +1,109 @@
+// Common device/host helpers for the imagetranslate_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/imt_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define IMT_WAVE 64
+#define IMT_DEVICE __device__ __forceinline__
+
+void imt_set_error(const char* fmt, ...);
+
+#define IMT_CHECK_ARG(cond, ...)                       \
+  do {                                                  \
+    if (!(cond)) {                                      \
+      imt_set_error(__VA_ARGS__);                       \
+      return IMT_ERR_BAD_ARG;                           \
+    }                                                   \
+  } while (0)
+
+#define IMT_CHECK_LAUNCH()                                                   \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      imt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,           \
+                    hipGetErrorString(e__));                                 \
+      return IMT_ERR_LAUNCH;                                                 \
+    }                                                                        \
+  } while (0)
+
+static inline int imt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- scalar conversions
+template <typename T> IMT_DEVICE float to_f32(T v);
+template <> IMT_DEVICE float to_f32<float>(float v) { return v; }
+template <> IMT_DEVICE float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> IMT_DEVICE T from_f32(float v);
+template <> IMT_DEVICE float from_f32<float>(float v) { return v; }
+template <> IMT_DEVICE bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 4-element vector of T <-> f32x4 (global/LDS, 8- or 16-byte accesses)
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  typedef f32x4 type;
+  static IMT_DEVICE f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static IMT_DEVICE void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+  typedef bf16x4 type;
+  static IMT_DEVICE f32x4 load(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+  }
+  static IMT_DEVICE void store(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = r;
+  }
+};
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+IMT_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+IMT_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- math
+IMT_DEVICE float gelu_erf(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+IMT_DEVICE float gelu_erf_grad(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(seed, idx): deterministic Bernoulli(1-p) per element index, recomputed identically in backward.
+IMT_DEVICE uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+IMT_DEVICE bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh /* p * 2^32 */) {
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = mix32(lo ^ (uint32_t)seed) ^ mix32(hi + (uint32_t)(seed >> 32) + 0x9e3779b9U);
+  h = mix32(h);
+  return h >= thresh;
+}
+static inline uint32_t dropout_thresh(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}

@@ -1,0 +1,445 @@
+// HBM-bound row kernels of the path: LayerNorm fwd/bwd, embedding gather / scatter-add, column sums
+// (bias gradients), row gather/scatter (non-pad target row select), casts.
+// One 64-lane wave owns one row; every lane moves 4 consecutive elements per access (8 B bf16 / 16 B fp32),
+// so a wave instruction covers 256 consecutive elements; row statistics are wave reductions.
+#include "common.hpp"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
+
+// ------------------------------------------------------------------------------------------- LayerNorm fwd
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int rows, int d, float eps, uint32_t thresh, float inv_keep,
+                                                     uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * d;
+  f32x4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d) v[i] = Vec4<T>::load(xr + c);
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < d) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mean; q += t * t; }
+    }
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  T* yr = y + (int64_t)row * d;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < d) {
+      const f32x4 g = Vec4<T>::load(gamma + c), b = Vec4<T>::load(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        if (thresh) o[e] = dropout_keep(seed, (uint64_t)row * d + c + e, thresh) ? o[e] * inv_keep : 0.f;
+      }
+      Vec4<T>::store(yr + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm bwd
+// Each wave walks `rows_per_wave` rows, keeps per-column partial dgamma/dbeta in registers, the 4 waves of
+// a block combine through LDS and issue one fp32 atomic per column per block.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                     int d, int rows_per_wave, uint32_t y_thresh, float y_inv_keep,
+                                                     uint64_t y_seed, T* __restrict__ dx_drop, uint32_t dx_thresh,
+                                                     float dx_inv_keep, uint64_t dx_seed) {
+  __shared__ float red[2][ROWS_PER_BLOCK][NCH * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  f32x4 g[NCH], ag[NCH], ab[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d) g[i] = Vec4<T>::load(gamma + c);
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int row_begin = (blockIdx.x * ROWS_PER_BLOCK + w) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int row = row_begin + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NCH], dyv[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dyv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) {
+        const f32x4 xv = Vec4<T>::load(x + (int64_t)row * d + c);
+        dyv[i] = Vec4<T>::load(dy + (int64_t)row * d + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (y_thresh) dyv[i][e] = dropout_keep(y_seed, (uint64_t)row * d + c + e, y_thresh) ? dyv[i][e] * y_inv_keep : 0.f;
+          xh[i][e] = (xv[e] - mu) * rs;
+          const float dg = dyv[i][e] * g[i][e];
+          s1 += dg;
+          s2 += dg * xh[i][e];
+          ag[i][e] += dyv[i][e] * xh[i][e];
+          ab[i][e] += dyv[i][e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < d) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[i][e] * g[i][e] - c1 - xh[i][e] * c2);
+        Vec4<T>::store(dx + (int64_t)row * d + c, o);
+        if (dx_drop) {
+          f32x4 o2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o2[e] = (!dx_thresh || dropout_keep(dx_seed, (uint64_t)row * d + c + e, dx_thresh)) ? o[e] * dx_inv_keep : 0.f;
+          Vec4<T>::store(dx_drop + (int64_t)row * d + c, o2);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][w][i * 256 + lane * 4 + e] = ag[i][e];
+      red[1][w][i * 256 + lane * 4 + e] = ab[i][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < ROWS_PER_BLOCK; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- embeddings
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                        const int64_t* __restrict__ type_ids, const T* __restrict__ word,
+                                                        const T* __restrict__ pos, const T* __restrict__ type,
+                                                        T* __restrict__ out, int n_tokens, int seq_len, int d, int vocab,
+                                                        int max_pos, int n_types) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (n >= n_tokens) return;
+  int64_t wi = ids[n];
+  int64_t pi = pos_ids ? pos_ids[n] : (int64_t)(n % seq_len);
+  int64_t ti = type_ids ? type_ids[n] : 0;
+  // clamp like a defensive gather: out-of-range ids would fault in the reference; here they read row 0
+  if (wi < 0 || wi >= vocab) wi = 0;
+  if (pi < 0 || pi >= max_pos) pi = 0;
+  if (ti < 0 || ti >= n_types) ti = 0;
+  const T* wr = word + wi * d;
+  const T* pr = pos + pi * d;
+  const T* tr = type + ti * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = Vec4<T>::load(wr + c) + Vec4<T>::load(pr + c);
+    v += Vec4<T>::load(tr + c);
+    Vec4<T>::store(out + (int64_t)n * d + c, v);
+  }
+}
+
+// scatter-add: one block walks TOKB tokens; thread owns columns tid, tid+256, ... (a wave's atomics of one
+// token row are 256 contiguous bytes -- the shape the memory-side atomic units run at full rate).
+// type-table rows (2 languages) are accumulated in registers and flushed once per block.
+template <typename T, int NT_REG>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                        const int64_t* __restrict__ type_ids, const T* __restrict__ dsum,
+                                                        float* __restrict__ dword, float* __restrict__ dpos,
+                                                        float* __restrict__ dtype_tab, int n_tokens, int seq_len, int d,
+                                                        int64_t pad_id, int tokb) {
+  const int n0 = blockIdx.x * tokb;
+  const int n1 = min(n_tokens, n0 + tokb);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float tacc[NT_REG];
+#pragma unroll
+    for (int k = 0; k < NT_REG; ++k) tacc[k] = 0.f;
+    for (int n = n0; n < n1; ++n) {
+      const float v = to_f32<T>(dsum[(int64_t)n * d + c]);
+      const int64_t wi = ids[n];
+      const int64_t pi = pos_ids ? pos_ids[n] : (int64_t)(n % seq_len);
+      const int64_t ti = type_ids ? type_ids[n] : 0;
+      if (wi != pad_id) atomicAdd(dword + wi * d + c, v);
+      atomicAdd(dpos + pi * d + c, v);
+      bool hit = false;
+#pragma unroll
+      for (int k = 0; k < NT_REG; ++k)
+        if (ti == k) { tacc[k] += v; hit = true; }
+      if (!hit) atomicAdd(dtype_tab + ti * d + c, v);
+    }
+#pragma unroll
+    for (int k = 0; k < NT_REG; ++k)
+      if (tacc[k] != 0.f) atomicAdd(dtype_tab + (int64_t)k * d + c, tacc[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- column sums
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ldx, int M, int N,
+                                                     float* __restrict__ out, int rows_per_block) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    const bool full = (c + 3 < N);
+    for (int r = r0 + w; r < r1; r += 4) {
+      if (full) acc += Vec4<T>::load(X + (int64_t)r * ldx + c);
+      else
+        for (int e = 0; e < 4 && c + e < N; ++e) acc[e] += to_f32<T>(X[(int64_t)r * ldx + c + e]);
+    }
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < N) {
+    f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    for (int e = 0; e < 4 && c + e < N; ++e) atomicAdd(out + c + e, s[e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- row gather / scatter
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, int64_t ldx, const int32_t* __restrict__ idx,
+                                                          T* __restrict__ out, int64_t ldo, int n_sel, int d, int scatter) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (r >= n_sel) return;
+  const int64_t src = scatter ? (int64_t)r : (int64_t)idx[r];
+  const int64_t dst = scatter ? (int64_t)idx[r] : (int64_t)r;
+  for (int c = lane * 4; c < d; c += 256) {
+    typedef typename Vec4<T>::type raw_t;
+    *reinterpret_cast<raw_t*>(out + dst * ldo + c) = *reinterpret_cast<const raw_t*>(x + src * ldx + c);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) Vec4<bf16_t>::store(dst + i, Vec4<float>::load(src + i));
+    else
+      for (int64_t e = i; e < n; ++e) dst[e] = (bf16_t)src[e];
+  }
+}
+
+// out = sigmoid(gate + 1e-7) * a + (1 - sigmoid(gate + 1e-7)) * b   (src/image_model.py:217-219, :364-366)
+template <typename T>
+__global__ __launch_bounds__(256) void gated_mix_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                        const T* __restrict__ gate, T* __restrict__ out, int64_t rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 av = Vec4<T>::load(a + r * d + c), bv = Vec4<T>::load(b + r * d + c), gv = Vec4<T>::load(gate + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = 1.0f / (1.0f + __expf(-(gv[e] + 1e-7f)));
+      o[e] = s * av[e] + (1.0f - s) * bv[e];
+    }
+    Vec4<T>::store(out + r * d + c, o);
+  }
+}
+
+template <typename T, int NCH>
+int ln_fwd_launch(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int rows, int d,
+                  float eps, float p, uint64_t seed, hipStream_t st) {
+  hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(imt_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, st,
+                     (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd, rows, d, eps, dropout_thresh(p),
+                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+template <typename T, int NCH>
+int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, void* dx,
+                  float* dgamma, float* dbeta, int rows, int d, float yp, uint64_t yseed, void* dx_drop, float dxp,
+                  uint64_t dxseed, hipStream_t st) {
+  // aim for ~512 blocks; each wave walks rows_per_wave rows
+  int rpw = imt_cdiv(rows, 512 * ROWS_PER_BLOCK);
+  if (rpw < 1) rpw = 1;
+  const int blocks = imt_cdiv(rows, rpw * ROWS_PER_BLOCK);
+  hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
+                     (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),
+                     yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),
+                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+#define IMT_DISPATCH_NCH(FN, T, d, ...)                                          \
+  do {                                                                           \
+    const int nch__ = imt_cdiv(d, 256);                                          \
+    if (nch__ <= 1) return FN<T, 1>(__VA_ARGS__);                                \
+    if (nch__ <= 2) return FN<T, 2>(__VA_ARGS__);                                \
+    if (nch__ <= 3) return FN<T, 3>(__VA_ARGS__);                                \
+    if (nch__ <= 4) return FN<T, 4>(__VA_ARGS__);                                \
+    imt_set_error("layernorm: d=%d > 1024 unsupported", d);                      \
+    return IMT_ERR_UNSUPPORTED;                                                  \
+  } while (0)
+
+}  // namespace
+
+extern "C" int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                                 float* rstd, int rows, int d, float eps, float dropout_p, uint64_t dropout_seed,
+                                 void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "layernorm_fwd: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0, "layernorm_fwd: d must be a positive multiple of 4");
+  if (rows <= 0) return IMT_OK;
+  IMT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IMT_F32) IMT_DISPATCH_NCH(ln_fwd_launch, float, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+  IMT_DISPATCH_NCH(ln_fwd_launch, bf16_t, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+}
+
+extern "C" int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
+                                 float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
+                                 uint64_t dx_dropout_seed, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "layernorm_bwd: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0, "layernorm_bwd: d must be a positive multiple of 4");
+  if (rows <= 0) return IMT_OK;
+  IMT_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IMT_F32)
+    IMT_DISPATCH_NCH(ln_bwd_launch, float, d, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, d, y_dropout_p,
+                     y_dropout_seed, dx_drop, dx_dropout_p, dx_dropout_seed, st);
+  IMT_DISPATCH_NCH(ln_bwd_launch, bf16_t, d, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, d, y_dropout_p,
+                   y_dropout_seed, dx_drop, dx_dropout_p, dx_dropout_seed, st);
+}
+
+extern "C" int imt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                             const void* word, const void* pos, const void* type, void* out, int n_tokens, int seq_len,
+                             int d, int vocab, int max_pos, int n_types, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "embed_fwd: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0 && seq_len > 0, "embed_fwd: bad dims");
+  if (n_tokens <= 0) return IMT_OK;
+  IMT_CHECK_ARG(ids && word && pos && type && out, "embed_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(imt_cdiv(n_tokens, ROWS_PER_BLOCK));
+  if (dtype == IMT_F32)
+    hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const float*)word,
+                       (const float*)pos, (const float*)type, (float*)out, n_tokens, seq_len, d, vocab, max_pos, n_types);
+  else
+    hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const bf16_t*)word,
+                       (const bf16_t*)pos, (const bf16_t*)type, (bf16_t*)out, n_tokens, seq_len, d, vocab, max_pos, n_types);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+extern "C" int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                             const void* dsum, float* dword, float* dpos, float* dtype_tab, int n_tokens, int seq_len,
+                             int d, int64_t pad_id, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "embed_bwd: bad dtype");
+  IMT_CHECK_ARG(d > 0 && seq_len > 0, "embed_bwd: bad dims");
+  if (n_tokens <= 0) return IMT_OK;
+  IMT_CHECK_ARG(ids && dsum && dword && dpos && dtype_tab, "embed_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int tokb = 16;
+  dim3 grid(imt_cdiv(n_tokens, tokb));
+  if (dtype == IMT_F32)
+    hipLaunchKernelGGL((embed_bwd_kernel<float, 4>), grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const float*)dsum,
+                       dword, dpos, dtype_tab, n_tokens, seq_len, d, pad_id, tokb);
+  else
+    hipLaunchKernelGGL((embed_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const bf16_t*)dsum,
+                       dword, dpos, dtype_tab, n_tokens, seq_len, d, pad_id, tokb);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+extern "C" int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "colsum: bad dtype");
+  if (M <= 0 || N <= 0) return IMT_OK;
+  IMT_CHECK_ARG(X && out && ldx % 4 == 0, "colsum: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = 64;
+  dim3 grid(imt_cdiv(N, 256), imt_cdiv(M, rpb));
+  if (dtype == IMT_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ldx, M, N, out, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, ldx, M, N, out, rpb);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+static int gather_scatter(int dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int n_sel,
+                          int d, int scatter, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "gather_rows: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "gather_rows: d/ld must be multiples of 4");
+  if (n_sel <= 0) return IMT_OK;
+  IMT_CHECK_ARG(x && idx && out, "gather_rows: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(imt_cdiv(n_sel, ROWS_PER_BLOCK));
+  if (dtype == IMT_F32)
+    hipLaunchKernelGGL(gather_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, idx, (float*)out, ldo, n_sel, d, scatter);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, idx, (bf16_t*)out, ldo, n_sel, d, scatter);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+extern "C" int imt_gather_rows(int dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo,
+                               int n_sel, int d, void* stream) {
+  return gather_scatter(dtype, x, ldx, idx, out, ldo, n_sel, d, 0, stream);
+}
+extern "C" int imt_scatter_rows(int dtype, const void* dout, int64_t ldo, const int32_t* idx, void* dx, int64_t ldx,
+                                int n_sel, int d, void* stream) {
+  return gather_scatter(dtype, dout, ldo, idx, dx, ldx, n_sel, d, 1, stream);
+}
+
+extern "C" int imt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (n <= 0) return IMT_OK;
+  IMT_CHECK_ARG(src && dst, "cast: null pointer");
+  int blocks = imt_cdiv(n, 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+extern "C" int imt_gated_mix(int dtype, const void* a, const void* b, const void* gate, void* out, int64_t rows, int d,
+                             void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "gated_mix: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0, "gated_mix: d must be a multiple of 4");
+  if (rows <= 0) return IMT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(imt_cdiv(rows, ROWS_PER_BLOCK));
+  if (dtype == IMT_F32)
+    hipLaunchKernelGGL(gated_mix_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)gate, (float*)out, rows, d);
+  else
+    hipLaunchKernelGGL(gated_mix_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)gate, (bf16_t*)out, rows, d);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}

@@ -1,0 +1,250 @@
+"""Tensor-level wrappers over the C ABI (no autograd here): each function takes torch CUDA tensors, passes
+raw device pointers / sizes / the current HIP stream to ``libimt_hip.so`` and returns torch tensors that own
+the outputs.  PyTorch supplies memory and streams only.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import IMT_AUX_DGELU, IMT_AUX_GELU_FWD, IMT_AUX_NONE, IMT_BF16, IMT_F32, IMT_NN, IMT_NT, IMT_TN  # noqa: F401
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return IMT_F32
+    if t.dtype == torch.bfloat16:
+        return IMT_BF16
+    raise TypeError("imagetranslate_amd supports float32 and bfloat16 tensors, got %s" % t.dtype)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.ImtError("imagetranslate_amd HIP ops need tensors on the GPU (no CPU fallback)")
+
+
+def _rowmajor(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
+    return t.stride(0)
+
+
+def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=None, aux_mode=IMT_AUX_NONE,
+         accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0):
+    """C = epilogue(op(A) op(B)); see include/imt_hip.h:imt_gemm."""
+    _req_cuda(A, B, out, bias, resid, aux)
+    if layout == IMT_NT:
+        M, K = A.shape; N = B.shape[0]; assert B.shape[1] == K
+    elif layout == IMT_NN:
+        M, K = A.shape; N = B.shape[1]; assert B.shape[0] == K
+    else:
+        K, M = A.shape; N = B.shape[1]; assert B.shape[0] == K
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
+        assert not accumulate and split_k == 1
+    a = L.GemmArgs()
+    a.dtype, a.layout = dt(A), layout
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda = A.data_ptr(), _rowmajor(A)
+    a.B, a.ldb = B.data_ptr(), _rowmajor(B)
+    a.C, a.ldc = out.data_ptr(), _rowmajor(out)
+    a.c_dtype = dt(out)
+    a.accumulate = int(accumulate)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.resid, a.ldr = (resid.data_ptr(), _rowmajor(resid)) if resid is not None else (None, 0)
+    a.aux, a.ldaux = (aux.data_ptr(), _rowmajor(aux)) if aux is not None else (None, 0)
+    a.aux_mode, a.split_k = aux_mode, split_k
+    a.alpha, a.dropout_p, a.dropout_seed = alpha, dropout_p, dropout_seed
+    L.check(L.load().imt_gemm(ctypes.byref(a), _stream()), "imt_gemm")
+    return out
+
+
+def colsum(X, out):
+    _req_cuda(X, out)
+    L.check(L.load().imt_colsum(dt(X), _p(X), _rowmajor(X), X.shape[0], X.shape[1], _p(out), _stream()), "imt_colsum")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0):
+    _req_cuda(x, gamma, beta)
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L.check(L.load().imt_layernorm_fwd(dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, d, eps,
+                                       dropout_p, dropout_seed, _stream()), "imt_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, y_dropout_p=0.0, y_dropout_seed=0, want_dx_drop=False,
+                  dx_dropout_p=0.0, dx_dropout_seed=0):
+    _req_cuda(dy, x, gamma, dgamma, dbeta)
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    dx_drop = torch.empty_like(x) if want_dx_drop else None
+    L.check(L.load().imt_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
+                                       _p(dbeta), rows, d, y_dropout_p, y_dropout_seed, _p(dx_drop), dx_dropout_p,
+                                       dx_dropout_seed, _stream()), "imt_layernorm_bwd")
+    return (dx, dx_drop) if want_dx_drop else dx
+
+
+def embed_fwd(ids, pos_ids, type_ids, word, pos, typ, seq_len):
+    _req_cuda(ids, word)
+    n = ids.numel()
+    d = word.shape[1]
+    out = torch.empty((n, d), device=word.device, dtype=word.dtype)
+    L.check(L.load().imt_embed_fwd(dt(word), _p(ids), _p(pos_ids), _p(type_ids), _p(word), _p(pos), _p(typ), _p(out), n,
+                                   seq_len, d, word.shape[0], pos.shape[0], typ.shape[0], _stream()), "imt_embed_fwd")
+    return out
+
+
+def embed_bwd(ids, pos_ids, type_ids, dsum, dword, dpos, dtype_tab, seq_len, pad_id):
+    _req_cuda(ids, dsum, dword, dpos, dtype_tab)
+    n, d = dsum.shape
+    L.check(L.load().imt_embed_bwd(dt(dsum), _p(ids), _p(pos_ids), _p(type_ids), _p(dsum), _p(dword), _p(dpos),
+                                   _p(dtype_tab), n, seq_len, d, pad_id, _stream()), "imt_embed_bwd")
+
+
+def _attn_args(q, k, v, B, H, Tq, Tk, head_dim, key_mask, query_mask, mask3d, causal, scale, dropout_p, dropout_seed):
+    a = L.AttnArgs()
+    a.dtype = dt(q)
+    a.B, a.H, a.Tq, a.Tk, a.head_dim = B, H, Tq, Tk, head_dim
+    a.Q, a.ldq = q.data_ptr(), _rowmajor(q)
+    a.K, a.ldk = k.data_ptr(), _rowmajor(k)
+    a.V, a.ldv = v.data_ptr(), _rowmajor(v)
+    a.key_mask = key_mask.data_ptr() if key_mask is not None else None
+    a.query_mask = query_mask.data_ptr() if query_mask is not None else None
+    a.mask3d = mask3d.data_ptr() if mask3d is not None else None
+    a.causal = int(causal)
+    a.scale = scale if scale is not None else 1.0 / math.sqrt(head_dim)
+    a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
+    return a
+
+
+def attention_fwd(q, k, v, B, H, Tq, Tk, head_dim, key_mask=None, query_mask=None, mask3d=None, causal=False,
+                  scale=None, dropout_p=0.0, dropout_seed=0):
+    """q: [B*Tq, >=H*head_dim] row-major view (heads merged), k/v: [B*Tk, ...]; masks uint8."""
+    _req_cuda(q, k, v, key_mask, query_mask, mask3d)
+    a = _attn_args(q, k, v, B, H, Tq, Tk, head_dim, key_mask, query_mask, mask3d, causal, scale, dropout_p, dropout_seed)
+    o = torch.empty((B * Tq, H * head_dim), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    a.O, a.ldo, a.lse = o.data_ptr(), o.stride(0), lse.data_ptr()
+    L.check(L.load().imt_attention_fwd(ctypes.byref(a), _stream()), "imt_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(do, q, k, v, o, lse, B, H, Tq, Tk, head_dim, key_mask=None, query_mask=None, mask3d=None,
+                  causal=False, scale=None, dropout_p=0.0, dropout_seed=0, dq=None, dk=None, dv=None):
+    _req_cuda(do, q, k, v, o, lse)
+    a = _attn_args(q, k, v, B, H, Tq, Tk, head_dim, key_mask, query_mask, mask3d, causal, scale, dropout_p, dropout_seed)
+    if dq is None:
+        dq = torch.empty((B * Tq, H * head_dim), device=q.device, dtype=q.dtype)
+    if dk is None:
+        dk = torch.empty((B * Tk, H * head_dim), device=q.device, dtype=q.dtype)
+    if dv is None:
+        dv = torch.empty((B * Tk, H * head_dim), device=q.device, dtype=q.dtype)
+    delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    a.O, a.ldo, a.lse = o.data_ptr(), _rowmajor(o), lse.data_ptr()
+    a.dO, a.lddo = do.data_ptr(), _rowmajor(do)
+    a.dQ, a.lddq = dq.data_ptr(), _rowmajor(dq)
+    a.dK, a.lddk = dk.data_ptr(), _rowmajor(dk)
+    a.dV, a.lddv = dv.data_ptr(), _rowmajor(dv)
+    a.delta = delta.data_ptr()
+    L.check(L.load().imt_attention_bwd(ctypes.byref(a), _stream()), "imt_attention_bwd")
+    return dq, dk, dv
+
+
+def gather_rows(x, idx):
+    _req_cuda(x, idx)
+    out = torch.empty((idx.numel(), x.shape[1]), device=x.device, dtype=x.dtype)
+    L.check(L.load().imt_gather_rows(dt(x), _p(x), _rowmajor(x), _p(idx), _p(out), out.stride(0) if out.numel() else x.shape[1],
+                                     idx.numel(), x.shape[1], _stream()), "imt_gather_rows")
+    return out
+
+
+def scatter_rows(dout, idx, dx):
+    _req_cuda(dout, idx, dx)
+    L.check(L.load().imt_scatter_rows(dt(dout), _p(dout), _rowmajor(dout) if dout.numel() else dx.shape[1], _p(idx), _p(dx),
+                                      _rowmajor(dx), idx.numel(), dx.shape[1], _stream()), "imt_scatter_rows")
+    return dx
+
+
+def log_softmax_fwd(logits):
+    _req_cuda(logits)
+    N, V = logits.shape
+    lp = torch.empty((N, V), device=logits.device, dtype=torch.float32)
+    lse = torch.empty(N, device=logits.device, dtype=torch.float32)
+    L.check(L.load().imt_log_softmax_fwd(dt(logits), _p(logits), _rowmajor(logits) if N else V, _p(lp), V, _p(lse), N, V,
+                                         _stream()), "imt_log_softmax_fwd")
+    return lp, lse
+
+
+def log_softmax_bwd(dlp, lp, out_dtype):
+    _req_cuda(dlp, lp)
+    N, V = lp.shape
+    out = torch.empty((N, V), device=lp.device, dtype=out_dtype)
+    L.check(L.load().imt_log_softmax_bwd(_p(dlp), _rowmajor(dlp) if N else V, _p(lp), V, dt(out), _p(out), V, N, V, _stream()),
+            "imt_log_softmax_bwd")
+    return out
+
+
+def smoothed_nll_fwd(lp, target, epsilon, ignore_index):
+    _req_cuda(lp, target)
+    N, V = lp.shape
+    loss = torch.empty((N, 1), device=lp.device, dtype=torch.float32)
+    L.check(L.load().imt_smoothed_nll_fwd(_p(lp), _rowmajor(lp) if N else V, _p(target), _p(loss), N, V, epsilon,
+                                          ignore_index, _stream()), "imt_smoothed_nll_fwd")
+    return loss
+
+
+def smoothed_nll_bwd(dloss, target, V, epsilon, ignore_index):
+    _req_cuda(dloss, target)
+    N = target.numel()
+    dlp = torch.empty((N, V), device=dloss.device, dtype=torch.float32)
+    L.check(L.load().imt_smoothed_nll_bwd(_p(dloss), _p(target), _p(dlp), V, N, V, epsilon, ignore_index, _stream()),
+            "imt_smoothed_nll_bwd")
+    return dlp
+
+
+def xent_fused_fwd_bwd(logits, target, epsilon, ignore_index, grad_scale):
+    """In place: logits <- dlogits; returns per-row loss."""
+    _req_cuda(logits, target)
+    N, V = logits.shape
+    loss = torch.empty(N, device=logits.device, dtype=torch.float32)
+    L.check(L.load().imt_xent_fused_fwd_bwd(dt(logits), _p(logits), _rowmajor(logits) if N else V, _p(target), _p(loss), N, V,
+                                            epsilon, ignore_index, grad_scale, _stream()), "imt_xent_fused_fwd_bwd")
+    return loss
+
+
+def sumsq(g, out):
+    _req_cuda(g, out)
+    L.check(L.load().imt_sumsq(_p(g), g.numel(), _p(out), _stream()), "imt_sumsq")
+    return out
+
+
+def clip_adam(p, g, m, v, p_bf16, sumsq_t, max_norm, grad_scale, lr, beta1, beta2, eps, step, zero_grad=True):
+    _req_cuda(p, g, m, v)
+    L.check(L.load().imt_clip_adam(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(sumsq_t), max_norm, grad_scale,
+                                   lr, beta1, beta2, eps, step, int(zero_grad), _stream()), "imt_clip_adam")
+
+
+def cast_f32_to_bf16(src, dst):
+    _req_cuda(src, dst)
+    L.check(L.load().imt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "imt_cast_f32_to_bf16")
+    return dst
+
+
+def gated_mix(a, b, gate):
+    _req_cuda(a, b, gate)
+    out = torch.empty_like(a)
+    L.check(L.load().imt_gated_mix(dt(a), _p(a), _p(b), _p(gate), _p(out), a.shape[0], a.shape[1], _stream()), "imt_gated_mix")
+    return out

@@ -1,0 +1,190 @@
+/*
+ * imt_hip.h -- C ABI of libimt_hip.so: the MI355X (gfx950) implementation of ImageTranslate's
+ * transformer encoder-decoder train-step hot path.
+ *
+ * The reference (rasoolims/ImageTranslate) has NO native/FFI layer: its hot path is Python nn.Modules on
+ * stock PyTorch + HuggingFace transformers==2.9.0.  Each entry point below therefore cites the reference
+ * Python (or restated HF-BERT 2.9.0) computation it replaces; the Python classes of the same names in
+ * imagetranslate_amd/ bind these through ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*.
+ *   - `stream` is a hipStream_t passed as void*; the library never allocates/frees device memory,
+ *     never synchronises the device, keeps no global state; all entry points are re-entrant per stream.
+ *   - return 0 on success, a negative IMT_ERR_* otherwise; imt_last_error() gives a thread-local message.
+ *   - dtype: IMT_F32 (parity mode, exact fp32 MFMA/VALU) or IMT_BF16 (bf16 storage, fp32 accumulate).
+ *     "T" below means the element type selected by `dtype`.  Gradients of PARAMETERS are always fp32
+ *     and are ACCUMULATED (+=) into the caller's flat gradient buffer.
+ *   - leading dimensions are in elements; rows must be 16-byte aligned (ld % 8 == 0 for bf16, % 4 for f32).
+ */
+#ifndef IMT_HIP_H
+#define IMT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMT_OK 0
+#define IMT_ERR_BAD_ARG (-1)
+#define IMT_ERR_UNSUPPORTED (-2)
+#define IMT_ERR_LAUNCH (-3)
+
+#define IMT_F32 0
+#define IMT_BF16 1
+
+int imt_version(void);
+const char* imt_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM (all nn.Linear fwd/bwd on the path)
+ * layout IMT_NT: C[M,N] = A[M,K] * B[N,K]^T   (y = x W^T : BertSelfAttention.query/key/value, *.dense,
+ *                                              BertOutputLayer.layer -- src/bert_seq2seq.py:6-12)
+ *        IMT_NN: C[M,N] = A[M,K] * B[K,N]     (dx = dy W)
+ *        IMT_TN: C[M,N] = A[K,M]^T * B[K,N]   (dW = dy^T x)
+ * epilogue, applied in this order to v = alpha * acc:
+ *   bias     : v += bias[n]                                   (T)
+ *   aux_mode : IMT_AUX_GELU_FWD  aux[m,n] = v ; v = gelu_erf(v)     (BertIntermediate, src/lm_config.py:7)
+ *              IMT_AUX_DGELU     v *= gelu_erf'(aux[m,n])
+ *   dropout  : v = keep(seed, m*N+n) ? v/(1-p) : 0            (hidden_dropout_prob, src/lm_config.py:8)
+ *   resid    : v += resid[m,n]                                (T)   (BertSelfOutput / BertOutput residual)
+ *   accumulate: v += C[m,n]
+ *   store as c_dtype (T or IMT_F32).  split_k > 1: fp32 atomicAdd of the raw partial products into C
+ *   (c_dtype must be IMT_F32; no other epilogue; C pre-initialised by the caller).
+ */
+#define IMT_NT 0
+#define IMT_NN 1
+#define IMT_TN 2
+#define IMT_AUX_NONE 0
+#define IMT_AUX_GELU_FWD 1
+#define IMT_AUX_DGELU 2
+
+typedef struct imt_gemm_args {
+  int32_t dtype, layout;
+  int32_t M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  int32_t c_dtype;
+  int32_t accumulate;
+  const void* bias;
+  const void* resid; int64_t ldr;
+  void* aux; int64_t ldaux;
+  int32_t aux_mode;
+  int32_t split_k;
+  float alpha;
+  float dropout_p;
+  uint64_t dropout_seed;
+} imt_gemm_args;
+int imt_gemm(const imt_gemm_args* a, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m,n]  -> bias gradients (fp32, accumulated). */
+int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm (torch.nn.LayerNorm, eps 1e-12)
+ * fwd: y = (x - mean) * rstd * gamma + beta ; saves mean/rstd (fp32, [rows]) for backward.
+ *      optional dropout on y (BertEmbeddings: dropout(LN(.))).
+ * bwd: dx = LN'(dy) ; dgamma/dbeta accumulated (fp32 atomics) ; optional second output
+ *      dx_drop = dropout-masked dx (grad w.r.t. the dense output that was dropped before the residual add).
+ */
+int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean,
+                      float* rstd, int rows, int d, float eps, float dropout_p, uint64_t dropout_seed,
+                      void* stream);
+int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
+                      float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
+                      uint64_t dx_dropout_seed, void* stream);
+
+/* ------------------------------------------------------------------ embeddings (HF BertEmbeddings)
+ * fwd: out[n,:] = word[ids[n]] + pos[pos_ids ? pos_ids[n] : n % seq_len] + type[type_ids[n]]   (pre-LN sum)
+ * bwd: scatter-add d(sum) into the three fp32 gradient tables; word rows with id == pad_id get no gradient
+ *      (nn.Embedding padding_idx).
+ */
+int imt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                  const void* word, const void* pos, const void* type, void* out, int n_tokens, int seq_len,
+                  int d, int vocab, int max_pos, int n_types, void* stream);
+int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                  const void* dsum, float* dword, float* dpos, float* dtype_tab, int n_tokens, int seq_len, int d,
+                  int64_t pad_id, void* stream);
+
+/* ------------------------------------------------------------------ attention (HF BertSelfAttention)
+ * scores = Q K^T * scale + additive mask ; P = softmax ; [dropout(P)] ; O = P V, heads merged in the output.
+ * Q/K/V are strided views: element (b, t, h, e) at base[(b*T + t)*ld + h*head_dim + e]
+ * mask semantics == (1 - m) * -10000.0 added to the scaled scores (src/bert_seq2seq.py:25-38, HF
+ * get_extended_attention_mask), m = AND of:
+ *   key_mask[b, j]   (uint8, nullable)  -- encoder pad mask / encoder_attention_mask
+ *   causal: j <= i   (flag)             -- future_mask / is_decoder 2-D mask
+ *   query_mask[b, i] (uint8, nullable)  -- the tgt_mask.unsqueeze(-1) factor of future_mask (src/seq2seq.py:14-17)
+ *   mask3d[b, i, j]  (uint8, nullable)  -- arbitrary 3-D tgt_attention_mask
+ * lse[b,h,i] (fp32) = log-sum-exp of the masked scaled scores, saved for backward.
+ */
+typedef struct imt_attn_args {
+  int32_t dtype;
+  int32_t B, H, Tq, Tk, head_dim;
+  const void* Q; int64_t ldq;
+  const void* K; int64_t ldk;
+  const void* V; int64_t ldv;
+  void* O; int64_t ldo;
+  float* lse;
+  const uint8_t* key_mask;
+  const uint8_t* query_mask;
+  const uint8_t* mask3d;
+  int32_t causal;
+  float scale;
+  float dropout_p;
+  uint64_t dropout_seed;
+  /* backward only */
+  const void* dO; int64_t lddo;
+  void* dQ; int64_t lddq;
+  void* dK; int64_t lddk;
+  void* dV; int64_t lddv;
+  float* delta; /* workspace [B,H,Tq] fp32: rowsum(dO * O) */
+} imt_attn_args;
+int imt_attention_fwd(const imt_attn_args* a, void* stream);
+int imt_attention_bwd(const imt_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------ row select (src/seq2seq.py:175-177)
+ * gather: out[r,:] = x[idx[r],:] ; scatter (its backward): dx[idx[r],:] = dout[r,:] (dx pre-zeroed by caller
+ * or zero_rest=1 to have the kernel write zeros to unselected rows given the inverse map).
+ */
+int imt_gather_rows(int dtype, const void* x, int64_t ldx, const int32_t* idx, void* out, int64_t ldo, int n_sel,
+                    int d, void* stream);
+int imt_scatter_rows(int dtype, const void* dout, int64_t ldo, const int32_t* idx, void* dx, int64_t ldx, int n_sel,
+                     int d, void* stream);
+
+/* ------------------------------------------------------------------ log-softmax + label-smoothed NLL
+ * (F.log_softmax src/seq2seq.py:179-180 ; SmoothedNLLLoss src/loss.py:10-27 ; .mean() train_image_mt.py:282)
+ * imt_log_softmax_fwd : lp = logits - logsumexp(logits) rowwise  (fp32 out, [N,V]); lse saved.
+ * imt_smoothed_nll_fwd: loss[r] = (1-eps)*(-lp[r,t]) + (eps/V)*(-sum_v lp[r,v]) ; 0 where t == ignore_index.
+ * imt_xent_fused_fwd_bwd: from raw logits (T, [N,V], in place): per-row loss and
+ *      dlogits = grad_scale * (softmax - ((1-eps)*onehot + eps/V)), 0 on ignored rows, written over logits.
+ */
+int imt_log_softmax_fwd(int dtype, const void* logits, int64_t ld, float* lp, int64_t ldlp, float* lse, int N, int V,
+                        void* stream);
+int imt_log_softmax_bwd(const float* dlp, int64_t lddlp, const float* lp, int64_t ldlp, int out_dtype, void* dlogits,
+                        int64_t ld, int N, int V, void* stream);
+int imt_smoothed_nll_fwd(const float* lp, int64_t ldlp, const int64_t* target, float* loss, int N, int V,
+                         float epsilon, int64_t ignore_index, void* stream);
+int imt_smoothed_nll_bwd(const float* dloss, const int64_t* target, float* dlp, int64_t lddlp, int N, int V,
+                         float epsilon, int64_t ignore_index, void* stream);
+int imt_xent_fused_fwd_bwd(int dtype, void* logits, int64_t ld, const int64_t* target, float* loss_rows, int N,
+                           int V, float epsilon, int64_t ignore_index, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * (clip_grad_norm_ train_image_mt.py:291 ; AdamInverseSqrtWithWarmup src/utils.py:105-156)
+ * imt_sumsq       : out[0] += sum(g^2) over n fp32 elements (out pre-zeroed by caller).
+ * imt_clip_adam   : clip_coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) ; g *= clip_coef ;
+ *                   Adam(beta1, beta2, eps, no weight decay, bias-corrected) on fp32 master params ;
+ *                   optionally writes the bf16 shadow copy ; optionally zeroes g.
+ *                   lr and step are read from the host args (one launch per step).
+ */
+int imt_sumsq(const float* g, int64_t n, float* out, void* stream);
+int imt_clip_adam(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* sumsq,
+                  float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, int64_t step,
+                  int zero_grad, void* stream);
+int imt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int imt_gated_mix(int dtype, const void* a, const void* b, const void* gate, void* out, int64_t rows, int d,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMT_HIP_H */

@@ -1,0 +1,91 @@
+"""Generates the committed golden fixtures.  Run in the BUILD container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+* loss_kat.json : known-answer vectors from the REFERENCE's own src/loss.py (SmoothedNLLLoss), imported from
+                  /root/reference/src -- inputs + expected per-row loss + d(mean loss)/dlogits through
+                  F.log_softmax.  This is data (inputs/outputs), no reference source is copied.
+* toy_seq2seq.pt: whole-model vectors from THIS repo's oracle (oracle/reference_model.py) on the toy
+                  configuration of SURVEY.md section 8(c) (d=128, h=4, ff=512, 2+2 layers, V=1000, B=8, S=T=32,
+                  dropout off, seed fixed): inputs, state_dict, encoder states, log-probs, loss, selected grads,
+                  three optimizer steps.  The reference's own tests pin nothing numeric for the model
+                  (parity unpinned) -- this fixture guards the oracle against drift.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def make_loss_kat():
+    sys.path.insert(0, "/root/reference/src")
+    import loss as ref_loss  # the reference's own file
+    g = torch.Generator().manual_seed(20240)
+    cases = []
+    specs = [
+        (torch.tensor([[1., 2., 3., 4.], [.5, -.5, 0., 2.], [0., 0., 0., 0.]]), torch.tensor([3, 1, 0]), 0.1, 0),
+        (torch.randn(6, 16, generator=g) * 2, torch.randint(0, 16, (6,), generator=g), 0.1, 0),
+        (torch.randn(5, 24, generator=g), torch.randint(1, 24, (5,), generator=g), 0.2, -100),
+    ]
+    for logits, tgt, eps, ign in specs:
+        z = logits.clone().requires_grad_(True)
+        lp = F.log_softmax(z, dim=-1)
+        crit = ref_loss.SmoothedNLLLoss(ignore_index=ign, epsilon=eps)
+        l = crit(lp, tgt)
+        l.mean().backward()
+        cases.append({"logits": logits.tolist(), "target": tgt.tolist(), "epsilon": eps, "ignore_index": ign,
+                      "loss": l.detach().view(-1).tolist(), "dlogits_mean": z.grad.tolist()})
+    json.dump({"source": "rasoolims/ImageTranslate src/loss.py SmoothedNLLLoss via F.log_softmax", "cases": cases},
+              open(os.path.join(HERE, "loss_kat.json"), "w"), indent=1)
+
+
+def make_toy():
+    from oracle import reference_model as R
+    torch.manual_seed(1234)
+    tp = R.SyntheticTextProcessor(1000)
+    m = R.Seq2Seq(tp, lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512,
+                  num_attention_heads=4)
+    m.eval()  # dropout off
+    B, S, T = 8, 32, 32
+    g = torch.Generator().manual_seed(99)
+    src = torch.randint(6, 1000, (B, S), generator=g)
+    tgt = torch.randint(6, 1000, (B, T), generator=g)
+    ls = torch.randint(16, S + 1, (B,), generator=g); lt = torch.randint(16, T + 1, (B,), generator=g)
+    src[torch.arange(S)[None] >= ls[:, None]] = 0
+    tgt[torch.arange(T)[None] >= lt[:, None]] = 0
+    src[:, 0] = 5; tgt[:, 0] = 6
+    batch = {"src_texts": src, "dst_texts": tgt, "src_pad_mask": src != 0, "dst_pad_mask": tgt != 0,
+             "src_langs": torch.zeros(B, dtype=torch.long), "dst_langs": torch.ones(B, dtype=torch.long)}
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    enc = m.encode(src, src != 0, batch["src_langs"].unsqueeze(-1).expand(-1, S))[0]
+    lp = m(src, tgt, src != 0, tgt != 0, batch["src_langs"], batch["dst_langs"], log_softmax=True)
+    targets = tgt[:, 1:].contiguous().view(-1)[(tgt != 0)[:, 1:].contiguous().view(-1)]
+    crit = R.SmoothedNLLLoss(ignore_index=0)
+    loss = crit(lp, targets).mean()
+    loss.backward()
+    named = dict(m.named_parameters())
+    grad_keys = ["encoder.embeddings.word_embeddings.weight",
+                 "encoder.encoder.layer.0.attention.self.query.weight",
+                 "decoder.decoder.layer.1.crossattention.self.key.weight",
+                 "output_layer.1.layer.weight", "output_layer.1.layer.bias"]
+    grads = {k: named[k].grad.clone() for k in grad_keys}
+    m.zero_grad()
+    opt = R.AdamInverseSqrtWithWarmup(m.parameters(), lr=1e-3, betas=(0.9, 0.98), warmup_updates=2)
+    losses = [R.train_step(m, opt, crit, batch)[0] for _ in range(3)]
+    torch.save({"batch": batch, "state_dict": sd0, "encoder_states": enc.detach(), "log_probs": lp.detach(),
+                "argmax": lp.argmax(-1), "loss": float(loss), "grads": grads, "step_losses": losses,
+                "updated_query_weight": named["encoder.encoder.layer.0.attention.self.query.weight"].detach().clone(),
+                "config": dict(vocab=1000, enc=2, dec=2, d=128, ff=512, heads=4, lr=1e-3, warmup=2)},
+               os.path.join(HERE, "toy_seq2seq.pt"))
+
+
+if __name__ == "__main__":
+    make_loss_kat()
+    make_toy()
+    print("wrote", os.listdir(HERE))

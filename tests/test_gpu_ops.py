@@ -1,0 +1,391 @@
+"""GPU parity tests of every C-ABI kernel against plain fp32 torch (CPU) restatements of the same op.
+
+fp32 mode: 1e-4 relative (north_star tolerance).  bf16 mode: inputs are rounded to bf16 first and the reference
+is computed in fp32 from the rounded inputs; tolerance 2.5e-2 relative to the output's max magnitude.
+All calls go through the C ABI (imagetranslate_amd.hip_ops -> ctypes -> libimt_hip.so).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _mk(shape, dtype, dev, scale=1.0, gen=None):
+    x = torch.randn(shape, generator=gen) * scale
+    xq = x.to(dtype)
+    return xq.to(dev), xq.float()  # device tensor, fp32 CPU copy of the (rounded) values
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_exact_integer_layout(cuda, dtype, layout):
+    """Small-integer operands (exact in bf16 and in fp32 accumulation): result must be BIT-EXACT.
+    Asymmetric data so that any swapped row/col or k mapping shows."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(128, 128, 64), (144, 200, 72), (16, 8, 8), (300, 264, 136)]:
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        B = torch.randint(-3, 4, (N, K), generator=g).float()
+        A[:, 0] += torch.arange(M).float() % 5
+        B[0, :] += torch.arange(K).float() % 3
+        ref = A @ B.t()
+        if layout == O.IMT_NT:
+            a_in, b_in = A, B
+        elif layout == O.IMT_NN:
+            a_in, b_in = A, B.t().contiguous()
+        else:
+            a_in, b_in = A.t().contiguous(), B.t().contiguous()
+        if (a_in.shape[1] % 8) or (b_in.shape[1] % 8):
+            continue
+        out = O.gemm(a_in.to(dtype).to(cuda), b_in.to(dtype).to(cuda), layout, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref), "layout %d dtype %s shape %s: max diff %g" % (
+            layout, dtype, (M, N, K), float((out.cpu() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_random(cuda, dtype, layout):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(2)
+    for (M, N, K) in [(256, 384, 512), (1000, 136, 264), (77, 1000, 128), (512, 512, 2048)]:
+        A, Af = _mk((M, K), dtype, cuda, 1.0, g)
+        B, Bf = _mk((N, K), dtype, cuda, 1.0, g)
+        ref = Af @ Bf.t()
+        if layout == O.IMT_NT:
+            a_in, b_in = A, B
+        elif layout == O.IMT_NN:
+            a_in, b_in = A, B.t().contiguous()
+        else:
+            a_in, b_in = A.t().contiguous(), B.t().contiguous()
+        if (a_in.shape[1] % 8) or (b_in.shape[1] % 8):
+            continue
+        out = O.gemm(a_in, b_in, layout)
+        assert_close(out, ref, 1e-5 if dtype == torch.float32 else 1e-2, "gemm %s %s" % (layout, (M, N, K)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(cuda, dtype):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 200, 264, 136
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    A, Af = _mk((M, K), dtype, cuda, 1.0, g)
+    B, Bf = _mk((N, K), dtype, cuda, 0.2, g)
+    bias, biasf = _mk((N,), dtype, cuda, 1.0, g)
+    R, Rf = _mk((M, N), dtype, cuda, 1.0, g)
+    base = Af @ Bf.t()
+    # bias
+    assert_close(O.gemm(A, B, O.IMT_NT, bias=bias), base + biasf, tol, "bias")
+    # bias + residual
+    assert_close(O.gemm(A, B, O.IMT_NT, bias=bias, resid=R), base + biasf + Rf, tol, "bias+resid")
+    # bias + gelu (aux = pre-activation)
+    aux = torch.empty((M, N), device=cuda, dtype=dtype)
+    h = O.gemm(A, B, O.IMT_NT, bias=bias, aux=aux, aux_mode=O.IMT_AUX_GELU_FWD)
+    assert_close(aux, base + biasf, tol, "gelu aux")
+    assert_close(h, F.gelu(base + biasf), tol, "gelu")
+    # dgelu: out = acc * gelu'(aux)
+    z = (base + biasf).to(dtype).float().requires_grad_(True)
+    F.gelu(z).sum().backward()
+    assert_close(O.gemm(A, B, O.IMT_NT, aux=aux, aux_mode=O.IMT_AUX_DGELU), base * z.grad, tol * 2, "dgelu")
+    # alpha + accumulate into fp32 C
+    C0 = torch.randn((M, N), generator=g)
+    C = C0.clone().to(cuda)
+    O.gemm(A, B, O.IMT_NT, out=C, accumulate=True, alpha=0.5)
+    assert_close(C, C0 + 0.5 * base, tol, "alpha+accumulate f32")
+    # split-K atomic accumulation (TN, the weight-gradient form): dW[N,K] += dY[M,N]^T X[M,K]
+    G0 = torch.randn((N, K), generator=g)
+    G = G0.clone().to(cuda)
+    dY, dYf = _mk((M, N), dtype, cuda, 1.0, g)
+    O.gemm(dY, A, O.IMT_TN, out=G, split_k=4)
+    assert_close(G, G0 + dYf.t() @ Af, tol, "split-k TN")
+    # strided views (sub-matrix of a wider buffer), as used for the fused QKV buffer
+    wide, widef = _mk((M, 3 * K), dtype, cuda, 1.0, g)
+    out = O.gemm(wide[:, K:2 * K], B, O.IMT_NT)
+    assert_close(out, widef[:, K:2 * K] @ Bf.t(), tol, "strided A")
+    # dropout epilogue: kept elements scaled by 1/(1-p), mask deterministic in (seed, index)
+    p = 0.25
+    d1 = O.gemm(A, B, O.IMT_NT, bias=bias, dropout_p=p, dropout_seed=1234).float().cpu()
+    d2 = O.gemm(A, B, O.IMT_NT, bias=bias, dropout_p=p, dropout_seed=1234).float().cpu()
+    assert torch.equal(d1, d2)
+    keep = d1 != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.02, frac
+    full = (base + biasf) / (1 - p)
+    assert_close(d1[keep], full[keep], tol, "dropout kept values")
+
+
+def test_gemm_bad_args(cuda):
+    from imagetranslate_amd import hip_ops as O
+    from imagetranslate_amd._lib import ImtError
+    A = torch.zeros((16, 12), device=cuda)  # K=12 ok for f32 (mult of 4) but lda fine; bf16 needs mult of 8
+    with pytest.raises(ImtError):
+        O.gemm(A.bfloat16(), A.bfloat16(), O.IMT_NT)
+    # empty problem is a no-op
+    out = O.gemm(torch.zeros((0, 16), device=cuda), torch.zeros((8, 16), device=cuda), O.IMT_NT)
+    assert out.shape == (0, 8)
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("d", [128, 512, 768])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm(cuda, dtype, d):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(4)
+    rows = 333
+    x, xf = _mk((rows, d), dtype, cuda, 2.0, g)
+    gamma, gf = _mk((d,), dtype, cuda, 1.0, g)
+    beta, bf = _mk((d,), dtype, cuda, 1.0, g)
+    dy, dyf = _mk((rows, d), dtype, cuda, 1.0, g)
+    xr = xf.clone().requires_grad_(True)
+    gr = gf.clone().requires_grad_(True)
+    br = bf.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (d,), gr, br, eps=1e-12)
+    ref.backward(dyf)
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    y, mean, rstd = O.layernorm_fwd(x, gamma, beta, 1e-12)
+    assert_close(y, ref, tol, "ln fwd")
+    assert_close(mean, xf.mean(-1), 1e-5, "ln mean")
+    dgamma = torch.zeros(d, device=cuda)
+    dbeta = torch.zeros(d, device=cuda)
+    dx = O.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta)
+    assert_close(dx, xr.grad, tol * 2, "ln dx")
+    assert_close(dgamma, gr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dgamma")
+    assert_close(dbeta, br.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dbeta")
+    # accumulation semantics: second call doubles the parameter grads
+    O.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta)
+    assert_close(dgamma, 2 * gr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dgamma accum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding(cuda, dtype):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(5)
+    V, P, NT, d, B, S = 1000, 512, 2, 128, 8, 32
+    word, wf = _mk((V, d), dtype, cuda, 1.0, g)
+    pos, pf = _mk((P, d), dtype, cuda, 1.0, g)
+    typ, tf = _mk((NT, d), dtype, cuda, 1.0, g)
+    ids = torch.randint(0, V, (B, S), generator=g)
+    ids[:, -5:] = 0  # pads
+    types = torch.randint(0, NT, (B, 1), generator=g).expand(B, S).contiguous()
+    pos_ids = torch.randint(0, P, (B, S), generator=g)
+    for use_pos in (False, True):
+        pid = pos_ids if use_pos else torch.arange(S).expand(B, S)
+        ref = wf[ids] + pf[pid] + tf[types]
+        out = O.embed_fwd(ids.to(cuda), pos_ids.to(cuda) if use_pos else None, types.to(cuda), word, pos, typ, S)
+        assert_close(out.view(B, S, d), ref, 1e-6 if dtype == torch.float32 else 1e-2, "embed fwd")
+        dsum, dsf = _mk((B * S, d), dtype, cuda, 1.0, g)
+        dw = torch.zeros((V, d), device=cuda); dp = torch.zeros((P, d), device=cuda); dtt = torch.zeros((NT, d), device=cuda)
+        O.embed_bwd(ids.to(cuda), pos_ids.to(cuda) if use_pos else None, types.to(cuda), dsum, dw, dp, dtt, S, 0)
+        rw = torch.zeros(V, d).index_add_(0, ids.view(-1), dsf); rw[0] = 0  # padding_idx row: no grad
+        rp = torch.zeros(P, d).index_add_(0, pid.reshape(-1), dsf)
+        rt = torch.zeros(NT, d).index_add_(0, types.view(-1), dsf)
+        assert_close(dw, rw, 1e-5, "embed dword")
+        assert_close(dp, rp, 1e-5, "embed dpos")
+        assert_close(dtt, rt, 1e-5, "embed dtype")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum_gather_scatter_mix_cast(cuda, dtype):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(6)
+    X, Xf = _mk((777, 264), dtype, cuda, 1.0, g)
+    out = torch.zeros(264, device=cuda)
+    O.colsum(X, out)
+    assert_close(out, Xf.sum(0), 1e-5, "colsum")
+    idx = torch.randperm(777, generator=g)[:300].sort().values.int()
+    sel = O.gather_rows(X, idx.to(cuda))
+    assert torch.equal(sel.float().cpu(), Xf[idx.long()])
+    dx = torch.zeros_like(X)
+    O.scatter_rows(sel, idx.to(cuda), dx)
+    ref = torch.zeros_like(Xf); ref[idx.long()] = Xf[idx.long()]
+    assert torch.equal(dx.float().cpu(), ref)
+    a, af = _mk((50, 128), dtype, cuda, 1.0, g); b, bf = _mk((50, 128), dtype, cuda, 1.0, g)
+    gate, gf = _mk((128,), dtype, cuda, 1.0, g)
+    s = torch.sigmoid(gf + 1e-7)
+    assert_close(O.gated_mix(a, b, gate), s * af + (1 - s) * bf, 1e-5 if dtype == torch.float32 else 1e-2, "gated mix")
+    src = torch.randn(1003, generator=g)
+    dst = torch.empty(1003, device=cuda, dtype=torch.bfloat16)
+    O.cast_f32_to_bf16(src.to(cuda), dst)
+    assert torch.equal(dst.cpu(), src.bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, B, H, Tq, Tk, dh, mask):
+    """HF BertSelfAttention math; mask: bool [B,Tq,Tk] (True = attend)."""
+    qh = q.view(B, Tq, H, dh).permute(0, 2, 1, 3)
+    kh = k.view(B, Tk, H, dh).permute(0, 2, 1, 3)
+    vh = v.view(B, Tk, H, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh) + ((1.0 - mask.float()) * -10000.0)[:, None]
+    p = F.softmax(s, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B * Tq, H * dh)
+
+
+@pytest.mark.parametrize("case", ["enc_keymask", "dec_causal_qmask", "cross_49", "mask3d", "long"])
+@pytest.mark.parametrize("dh", [32, 64])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_fwd_bwd(cuda, dtype, dh, case):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(7)
+    B, H = 3, 4
+    Tq, Tk = {"enc_keymask": (32, 32), "dec_causal_qmask": (127, 127), "cross_49": (31, 49), "mask3d": (20, 70),
+              "long": (130, 200)}[case]
+    d = H * dh
+    # q/k/v live in one wider buffer (fused QKV layout) for the self-attention cases
+    q, qf = _mk((B * Tq, d), dtype, cuda, 1.0, g)
+    k, kf = _mk((B * Tk, d), dtype, cuda, 1.0, g)
+    v, vf = _mk((B * Tk, d), dtype, cuda, 1.0, g)
+    do, dof = _mk((B * Tq, d), dtype, cuda, 1.0, g)
+    key_mask = query_mask = mask3d = None
+    causal = False
+    if case in ("enc_keymask", "cross_49", "long"):
+        lens = torch.randint(Tk // 2, Tk + 1, (B,), generator=g)
+        key_mask = (torch.arange(Tk)[None] < lens[:, None])
+        mask = key_mask[:, None, :].expand(B, Tq, Tk)
+    elif case == "dec_causal_qmask":
+        lens = torch.randint(Tq // 2, Tq + 1, (B,), generator=g)
+        query_mask = (torch.arange(Tq)[None] < lens[:, None])
+        causal = True
+        mask = torch.tril(torch.ones(Tq, Tk, dtype=torch.bool))[None] & query_mask[:, :, None]
+    else:
+        mask3d = torch.rand((B, Tq, Tk), generator=g) > 0.3
+        mask = mask3d
+    u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous().to(cuda)
+    o, lse = O.attention_fwd(q, k, v, B, H, Tq, Tk, dh, key_mask=u8(key_mask), query_mask=u8(query_mask),
+                             mask3d=u8(mask3d), causal=causal)
+    qr, kr, vr = [t.clone().requires_grad_(True) for t in (qf, kf, vf)]
+    ref = _attn_ref(qr, kr, vr, B, H, Tq, Tk, dh, mask)
+    ref.backward(dof)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(o, ref, tol, "attn fwd " + case)
+    dq, dk, dv = O.attention_bwd(do, q, k, v, o, lse, B, H, Tq, Tk, dh, key_mask=u8(key_mask), query_mask=u8(query_mask),
+                                 mask3d=u8(mask3d), causal=causal)
+    tolb = 5e-5 if dtype == torch.float32 else 3e-2
+    assert_close(dq, qr.grad, tolb, "attn dq " + case)
+    assert_close(dk, kr.grad, tolb, "attn dk " + case)
+    assert_close(dv, vr.grad, tolb, "attn dv " + case)
+
+
+def test_attention_fused_qkv_views_and_dropout(cuda):
+    """Strided q/k/v views into one [N,3d] buffer; dropout: deterministic, backward consistent with forward
+    (finite-difference-free check: dropout with p -> compare against reference using the recovered mask)."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(8)
+    B, H, T, dh = 2, 4, 48, 32
+    d = H * dh
+    qkv = torch.randn((B * T, 3 * d), generator=g).to(cuda)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    o, lse = O.attention_fwd(q, k, v, B, H, T, T, dh, causal=True)
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None].expand(B, T, T)
+    ref = _attn_ref(q.cpu().contiguous(), k.cpu().contiguous(), v.cpu().contiguous(), B, H, T, T, dh, mask)
+    assert_close(o, ref, 2e-5, "fused-qkv views")
+    # dropout determinism + expected keep fraction via V = identity-like probe
+    o1, _ = O.attention_fwd(q, k, v, B, H, T, T, dh, causal=True, dropout_p=0.5, dropout_seed=99)
+    o2, _ = O.attention_fwd(q, k, v, B, H, T, T, dh, causal=True, dropout_p=0.5, dropout_seed=99)
+    o3, _ = O.attention_fwd(q, k, v, B, H, T, T, dh, causal=True, dropout_p=0.5, dropout_seed=100)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    # backward with dropout: compare to autograd through an explicit-mask reference.  Recover the mask by
+    # running the kernel with V = one-hot columns (P_drop rows appear directly).
+    Tk = T
+    eye = torch.zeros((B * Tk, d))
+    for h in range(H):
+        for j in range(min(Tk, dh)):
+            eye.view(B, Tk, H, dh)[:, j, h, j] = 1.0
+    pd, _ = O.attention_fwd(q, k, eye.to(cuda), B, H, T, Tk, dh, causal=True, dropout_p=0.5, dropout_seed=99)
+    pd = pd.cpu().view(B, T, H, dh).permute(0, 2, 1, 3)[..., :min(Tk, dh)]  # P_drop[b,h,i,j<dh]
+    qf, kf = q.cpu().contiguous(), k.cpu().contiguous()
+    s = (qf.view(B, T, H, dh).permute(0, 2, 1, 3) @ kf.view(B, T, H, dh).permute(0, 2, 3, 1)) / math.sqrt(dh)
+    s = s + ((1.0 - mask.float()) * -10000.0)[:, None]
+    p = F.softmax(s, -1)[..., :min(Tk, dh)]
+    keep = pd != 0
+    assert_close(pd[keep], (p / 0.5)[keep], 1e-4, "dropped probs")
+    visible = p > 1e-6
+    frac = keep[visible].float().mean().item()
+    assert abs(frac - 0.5) < 0.05, frac
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_log_softmax_and_smoothed_nll(cuda, dtype):
+    from imagetranslate_amd import hip_ops as O
+    from oracle.reference_model import SmoothedNLLLoss
+    g = torch.Generator().manual_seed(9)
+    N, V = 37, 1000
+    z, zf = _mk((N, V), dtype, cuda, 3.0, g)
+    tgt = torch.randint(1, V, (N,), generator=g)
+    tgt[::7] = 0  # ignored rows
+    zr = zf.clone().requires_grad_(True)
+    lp_ref = F.log_softmax(zr, dim=-1)
+    loss_ref = SmoothedNLLLoss(ignore_index=0)(lp_ref, tgt)
+    loss_ref.mean().backward()
+    lp, lse = O.log_softmax_fwd(z)
+    assert_close(lp, lp_ref, 1e-6, "log_softmax")
+    loss = O.smoothed_nll_fwd(lp, tgt.to(cuda), 0.1, 0)
+    assert loss.shape == (N, 1)
+    assert_close(loss, loss_ref, 1e-5, "smoothed nll")
+    dloss = torch.full((N, 1), 1.0 / N, device=cuda)
+    dlp = O.smoothed_nll_bwd(dloss, tgt.to(cuda), V, 0.1, 0)
+    dz = O.log_softmax_bwd(dlp, lp, torch.float32)
+    assert_close(dz, zr.grad, 1e-4, "dlogits (2-kernel path)")
+    # fused
+    z2 = z.clone()
+    lrows = O.xent_fused_fwd_bwd(z2, tgt.to(cuda), 0.1, 0, 1.0 / N)
+    assert_close(lrows.view(N, 1), loss_ref, 1e-5 if dtype == torch.float32 else 1e-4, "fused loss")
+    assert_close(z2, zr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "fused dlogits")
+
+
+def test_loss_known_answer(cuda):
+    """Known-answer vector produced by the reference's own src/loss.py (tests/golden/loss_kat.json)."""
+    import json
+    import os
+    from imagetranslate_amd import hip_ops as O
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "loss_kat.json")))
+    for case in kat["cases"]:
+        logits = torch.tensor(case["logits"], dtype=torch.float32)
+        tgt = torch.tensor(case["target"], dtype=torch.long)
+        lp, _ = O.log_softmax_fwd(logits.to(cuda))
+        loss = O.smoothed_nll_fwd(lp, tgt.to(cuda), case["epsilon"], case["ignore_index"])
+        assert_close(loss.view(-1), torch.tensor(case["loss"]), 1e-6, "loss KAT")
+        z = logits.to(cuda).clone()
+        n = len(case["target"])
+        O.xent_fused_fwd_bwd(z, tgt.to(cuda), case["epsilon"], case["ignore_index"], 1.0 / n)
+        assert_close(z, torch.tensor(case["dlogits_mean"]), 1e-5, "loss KAT grad")
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_clip_adam_matches_torch(cuda):
+    from imagetranslate_amd import hip_ops as O
+    from oracle.reference_model import AdamInverseSqrtWithWarmup
+    g = torch.Generator().manual_seed(10)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = AdamInverseSqrtWithWarmup([pr], lr=1e-3, betas=(0.9, 0.98), warmup_updates=3)
+    p = torch.zeros(n + 1, device=cuda)[:n]  # (keeps 16-B alignment: offset 0)
+    p.copy_(p0)
+    m = torch.zeros(n, device=cuda); v = torch.zeros(n, device=cuda)
+    pb = torch.empty(n, device=cuda, dtype=torch.bfloat16)
+    from oracle.reference_model import inverse_sqrt_lr
+    lr = 1e-7
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (5.0 if step % 2 else 0.001)
+        pr.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gdev = grad.to(cuda)
+        ss = torch.zeros(1, device=cuda)
+        O.sumsq(gdev, ss)
+        assert_close(ss, (grad.double() ** 2).sum().float().view(1), 1e-5, "sumsq")
+        O.clip_adam(p, gdev, m, v, pb, ss, 1.0, 1.0, lr, 0.9, 0.98, 1e-8, step, zero_grad=True)
+        lr = inverse_sqrt_lr(step, 1e-3, 3)
+        assert_close(p, pr.detach(), 1e-5, "adam step %d" % step)
+        assert float(gdev.abs().max()) == 0.0
+        assert torch.equal(pb.cpu(), p.cpu().bfloat16())
