@@ -63,20 +63,26 @@ template <int RB> IMT_DEVICE f32x4 lds_frag_kstrided_f32(const char* tile, int k
 #ifndef IMT_NO_TR_READ
 // ds_read_b64_tr_b16 (T10): within a 16-lane group, lane 4q+p supplies the address of row q, columns
 // 4p..4p+3 of a 4x16 block; lane i receives column i, row e in element e.  EXEC must be all ones.
+// (Verified on MI355X with tools/probe_tr.hip / tools/probe_frag.hip.)
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+IMT_DEVICE s16x4 tr_read16(const char* addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<char*>(addr)));
+}
+IMT_DEVICE bf16x8 join_tr(s16x4 lo, s16x4 hi) {
+  // whole-vector bit cast (per-element bit_cast of vector lanes miscompiled: every lane got element 0)
+  const s16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, w);
+}
 template <int RB> IMT_DEVICE bf16x8 lds_frag_kstrided_bf16(const char* tile, int krow0, int col0) {
   const int l = threadIdx.x & 63, i = l & 15, g = l >> 4, q = i >> 2, p = i & 3;
   const int col = col0 + 4 * p;
-  bf16x8 v;
+  s16x4 t[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int kr = krow0 + 8 * g + 4 * h + q;
-    const char* addr = tile + tile_off<RB>(kr, col >> 3) + ((col & 7) << 1);
-    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(const_cast<char*>(addr)));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[4 * h + e] = __builtin_bit_cast(bf16_t, t[e]);
+    t[h] = tr_read16(tile + tile_off<RB>(kr, col >> 3) + ((col & 7) << 1));
   }
-  return v;
+  return join_tr(t[0], t[1]);
 }
 #else
 // Debug fallback: 8 scalar 2-byte LDS reads (no transposed read); used to cross-check the tr path.
@@ -115,17 +121,13 @@ template <int RB> IMT_DEVICE f32x4 lds_frag_kperm_f32(const char* tile, int krow
 template <int RB> IMT_DEVICE bf16x8 lds_frag_kperm_bf16(const char* tile, int krow_tile0, int col0) {
   const int l = threadIdx.x & 63, i = l & 15, g = l >> 4, q = i >> 2, p = i & 3;
   const int col = col0 + 4 * p;
-  bf16x8 v;
+  s16x4 t[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int kr = krow_tile0 + 16 * h + 4 * g + q;
-    const char* addr = tile + tile_off<RB>(kr, col >> 3) + ((col & 7) << 1);
-    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(const_cast<char*>(addr)));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[4 * h + e] = __builtin_bit_cast(bf16_t, t[e]);
+    t[h] = tr_read16(tile + tile_off<RB>(kr, col >> 3) + ((col & 7) << 1));
   }
-  return v;
+  return join_tr(t[0], t[1]);
 }
 #else
 template <int RB> IMT_DEVICE bf16x8 lds_frag_kperm_bf16(const char* tile, int krow_tile0, int col0) {

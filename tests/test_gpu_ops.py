@@ -258,6 +258,12 @@ def test_attention_fwd_bwd(cuda, dtype, dh, case):
     else:
         mask3d = torch.rand((B, Tq, Tk), generator=g) > 0.3
         mask = mask3d
+    # Fully masked (pad) query rows see a uniform -10000 shift: their softmax is ill-conditioned in fp32
+    # (ulp(1e4) ~ 1e-3) and the model discards them (src/seq2seq.py:175-177), so they are excluded from the
+    # comparison and carry no upstream gradient -- exactly as in the real model.
+    valid_q = torch.ones(B * Tq, dtype=torch.bool) if query_mask is None else query_mask.reshape(-1)
+    dof = dof * valid_q[:, None]
+    do = (do.float() * valid_q[:, None].to(cuda)).to(dtype)
     u8 = lambda m: None if m is None else m.to(torch.uint8).contiguous().to(cuda)
     o, lse = O.attention_fwd(q, k, v, B, H, Tq, Tk, dh, key_mask=u8(key_mask), query_mask=u8(query_mask),
                              mask3d=u8(mask3d), causal=causal)
@@ -265,11 +271,11 @@ def test_attention_fwd_bwd(cuda, dtype, dh, case):
     ref = _attn_ref(qr, kr, vr, B, H, Tq, Tk, dh, mask)
     ref.backward(dof)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
-    assert_close(o, ref, tol, "attn fwd " + case)
+    assert_close(o.cpu()[valid_q], ref[valid_q], tol, "attn fwd " + case)
     dq, dk, dv = O.attention_bwd(do, q, k, v, o, lse, B, H, Tq, Tk, dh, key_mask=u8(key_mask), query_mask=u8(query_mask),
                                  mask3d=u8(mask3d), causal=causal)
     tolb = 5e-5 if dtype == torch.float32 else 3e-2
-    assert_close(dq, qr.grad, tolb, "attn dq " + case)
+    assert_close(dq.cpu()[valid_q], qr.grad[valid_q], tolb, "attn dq " + case)
     assert_close(dk, kr.grad, tolb, "attn dk " + case)
     assert_close(dv, vr.grad, tolb, "attn dv " + case)
 
