@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: BASELINE.json's metric -- train tokens/sec (whole node) of the 6L enc-dec d=512
+seq128 b64 MT train step -- on synthetic random-token batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch per rank: forward, label-smoothed NLL, backward, RCCL
+gradient all-reduce (N > 1, overlapped), global grad-norm clip, Adam -- the body of ImageMTTrainer.train_epoch
+(src/train_image_mt.py:239-295).  Tokens = non-pad TARGET tokens, the reference's own count (:256,:302-306).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+
+CONFIGS = {
+    # name: (B, S, T, d, heads, ff, enc, dec, V)
+    "c1": dict(B=64, S=128, T=128, d=512, heads=8, ff=2048, enc=6, dec=6, V=30000,
+               desc="6L/6L enc-dec d=512 h=8 ff=2048 V=30000, src[64,128] tgt[64,128], synthetic random-token MT"),
+    "toy": dict(B=8, S=32, T=32, d=128, heads=4, ff=512, enc=2, dec=2, V=1000,
+                desc="2L/2L d=128 h=4 ff=512 V=1000 (plumbing)"),
+}
+
+
+def algorithmic_flops(c):
+    """2*M*N*K per GEMM (forward), x3 for a train step; SURVEY section 8(d) counting (masked positions dense)."""
+    B, S, T1, d, ff, V, h = c["B"], c["S"], c["T"] - 1, c["d"], c["ff"], c["V"], c["heads"]
+    Ns, Nt = B * S, B * T1
+    enc = c["enc"] * (2 * Ns * d * 3 * d + 2 * Ns * d * d + 4 * B * S * S * d + 4 * Ns * d * ff)
+    dec = c["dec"] * (2 * Nt * d * 3 * d + 2 * Nt * d * d + 4 * B * T1 * T1 * d            # self
+                      + 2 * Nt * d * d + 2 * Ns * d * 2 * d + 2 * Nt * d * d + 4 * B * T1 * S * d  # cross
+                      + 4 * Nt * d * ff)
+    out = 2 * Nt * d * V
+    return 3.0 * (enc + dec + out)
+
+
+def make_batch(c, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    B, S, T, V = c["B"], c["S"], c["T"], c["V"]
+    src = torch.randint(6, V, (B, S), generator=g)
+    tgt = torch.randint(6, V, (B, T), generator=g)
+    src[:, 0], tgt[:, 0] = 5, 6          # language tags first (textprocessor.py:29-30), </s> last
+    src[:, -1], tgt[:, -1] = 4, 4
+    b = {"src_texts": src, "dst_texts": tgt, "src_pad_mask": src != 0, "dst_pad_mask": tgt != 0,
+         "src_langs": torch.zeros(B, dtype=torch.long), "dst_langs": torch.ones(B, dtype=torch.long)}
+    return {k: v.to(device) if k not in ("src_langs", "dst_langs") else v for k, v in b.items()}
+
+
+def build_model(c, dtype, device):
+    from imagetranslate_amd.seq2seq import Seq2Seq
+    from imagetranslate_amd.textprocessor import SyntheticTextProcessor
+    tp = SyntheticTextProcessor(c["V"])
+    torch.manual_seed(1234)
+    m = Seq2Seq(tp, lang_dec=False, enc_layer=c["enc"], dec_layer=c["dec"], embed_dim=c["d"], intermediate_dim=c["ff"],
+                num_attention_heads=c["heads"])
+    m.set_compute_dtype(dtype)
+    return m.to(device)
+
+
+def cpu_baseline(c, seconds_budget=25.0):
+    """Reference-equivalent CPU path (this repo's oracle, kind 'port') timed on the host cores on a bounded sample
+    of the same workload: the C1 model with a batch of 8 of the 64 sentences, full train step."""
+    from oracle import reference_model as R
+    try:
+        cores = len(os.sched_getaffinity(0))  # the cgroup/affinity share, not the host's core count
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, cores))
+    print("[bench] cpu_baseline: oracle train step on %d host threads ..." % cores, file=sys.stderr, flush=True)
+    Bs = max(1, c["B"] // 8)
+    tp = R.SyntheticTextProcessor(c["V"])
+    torch.manual_seed(1234)
+    m = R.Seq2Seq(tp, lang_dec=False, enc_layer=c["enc"], dec_layer=c["dec"], embed_dim=c["d"], intermediate_dim=c["ff"],
+                  num_attention_heads=c["heads"]).train()
+    opt = R.AdamInverseSqrtWithWarmup(m.parameters(), lr=1e-4, betas=(0.9, 0.98), warmup_updates=4000)
+    crit = R.SmoothedNLLLoss(ignore_index=0)
+    cs = dict(c, B=Bs)
+    b = make_batch(cs, 1234, "cpu")
+    tw = time.time()
+    R.train_step(m, opt, crit, b)  # warm-up
+    print("[bench] cpu_baseline: warm-up step %.1f s" % (time.time() - tw), file=sys.stderr, flush=True)
+    t0, n, toks = time.time(), 0, 0
+    while n < 3 and (time.time() - t0) < seconds_budget:
+        _, nt = R.train_step(m, opt, crit, b)
+        toks += nt
+        n += 1
+        print("[bench] cpu_baseline: step %d done at %.1f s" % (n, time.time() - t0), file=sys.stderr, flush=True)
+    dt = time.time() - t0
+    return {"value": toks / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps of the C1 model on %d of the 64 sentences ([%d,%d] src/tgt), fp32 torch eager, "
+                      "dropout 0.1 (oracle/reference_model.py)" % (n, Bs, Bs, c["S"])}
+
+
+def profile_pass(step_fn, steps=2):
+    """Re-run a few steps with the library's per-launch HIP-event profiler on; returns per-kind rows."""
+    from imagetranslate_amd import _lib as L
+    lib = L.load()
+    torch.cuda.synchronize()
+    lib.imt_prof_enable(1)
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    rows = (L.ProfRow * 64)()
+    n = lib.imt_prof_report(rows, 64)
+    lib.imt_prof_enable(0)
+    out = []
+    for i in range(n):
+        r = rows[i]
+        out.append({"kind": r.kind.decode(), "launches": int(r.launches) // steps, "ms": r.total_ms / steps,
+                    "flops": r.flops / steps, "bytes": r.bytes / steps})
+    return sorted(out, key=lambda r: -r["ms"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from imagetranslate_amd.parallel import GradSync, train_step
+    from imagetranslate_amd.utils import AdamInverseSqrtWithWarmup
+
+    c = CONFIGS[args.config]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = build_model(c, dtype, device)
+    model.train(not args.no_dropout)  # reference trains with dropout 0.1 (lm_config.py:6,8)
+    opt = AdamInverseSqrtWithWarmup(model.parameters(), lr=1e-4, betas=(0.9, 0.98), warmup_updates=4000)
+    batch = make_batch(c, 1234 + rank, device)  # each rank its own batch (weak scaling: global batch = 64 * N)
+    sync = GradSync(model) if world > 1 else None
+    ntok_step = int(batch["dst_pad_mask"][:, 1:].sum())
+
+    def step():
+        return train_step(model, opt, batch, sync=sync, clip=1.0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+
+    rows = profile_pass(step) if rank == 0 else []
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = ntok_step * world * args.steps / elapsed
+        flops = algorithmic_flops(c)
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        # dominant kernel = the kernel kind with the largest summed device time in the instrumented pass
+        gemm_rows = [r for r in rows if r["kind"].startswith("gemm_")]
+        dom = max(gemm_rows, key=lambda r: r["ms"]) if gemm_rows else None
+        roofline = None
+        if dom is not None:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None,
+                        "launches_per_step": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / max(1, dom["launches"]), 2),
+                        "step_frac": round(flops / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+                        "step_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2)}
+        out = {
+            "metric": "train tokens/sec (whole node), 6L enc-dec d=512 seq128 b64, 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": c["desc"], "global_batch": c["B"] * world, "seq_len": c["S"],
+                       "target_tokens_per_step": ntok_step * world, "parallelism": "dp%d" % world,
+                       "dropout": 0.0 if args.no_dropout else 0.1, "algorithmic_tflop_per_step": round(flops / 1e12, 3),
+                       "final_loss": round(loss_val, 4)},
+            "roofline": roofline,
+        }
+        print("[bench] gpu: %.1f tokens/s, %.3f ms/step" % (value, ms_per_step), file=sys.stderr, flush=True)
+        if args.breakdown:
+            tot = sum(r["ms"] for r in rows)
+            print("%-22s %8s %10s %9s %9s" % ("kernel", "launches", "ms/step", "TFLOP/s", "GB/s"), file=sys.stderr)
+            for r in rows:
+                print("%-22s %8d %10.3f %9.1f %9.1f" % (r["kind"], r["launches"], r["ms"], r["flops"] / (r["ms"] * 1e9 + 1e-30),
+                                                        r["bytes"] / (r["ms"] * 1e6 + 1e-30)), file=sys.stderr)
+            print("sum of kernel time %.3f ms / step (instrumented pass)" % tot, file=sys.stderr, flush=True)
+        out["cpu_baseline"] = cpu_baseline(c) if (world == 1 and not args.no_cpu_baseline) else None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

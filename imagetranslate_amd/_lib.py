@@ -30,6 +30,7 @@ class GemmArgs(Structure):
         ("aux_mode", c_int32), ("split_k", c_int32),
         ("alpha", c_float), ("dropout_p", c_float),
         ("dropout_seed", c_uint64),
+        ("alpha_dev", c_void_p),
     ]
 
 
@@ -53,13 +54,57 @@ class AttnArgs(Structure):
     ]
 
 
+class ProfRow(Structure):
+    _fields_ = [("kind", ctypes.c_char * 48), ("launches", c_int64), ("total_ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
+class AttnBlock(Structure):
+    _fields_ = [("qkv_w", c_int64), ("qkv_b", c_int64), ("o_w", c_int64), ("o_b", c_int64), ("ln_g", c_int64),
+                ("ln_b", c_int64)]
+
+
+class LayerDesc(Structure):
+    _fields_ = [("self_attn", AttnBlock), ("cross_attn", AttnBlock),
+                ("ff1_w", c_int64), ("ff1_b", c_int64), ("ff2_w", c_int64), ("ff2_b", c_int64),
+                ("ln2_g", c_int64), ("ln2_b", c_int64)]
+
+
+class StackDesc(Structure):
+    _fields_ = [
+        ("dtype", c_int32),
+        ("d", c_int32), ("heads", c_int32), ("ff", c_int32), ("vocab", c_int32), ("max_pos", c_int32),
+        ("n_types", c_int32), ("n_layers", c_int32),
+        ("is_decoder", c_int32), ("reserved", c_int32),
+        ("pad_id", c_int64),
+        ("ln_eps", c_float), ("hidden_dropout", c_float), ("attn_dropout", c_float), ("reserved_f", c_float),
+        ("emb_word", c_int64), ("emb_pos", c_int64), ("emb_type", c_int64), ("emb_ln_g", c_int64), ("emb_ln_b", c_int64),
+        ("layers", POINTER(LayerDesc)),
+        ("params", c_void_p),
+        ("grads", c_void_p),
+    ]
+
+
+class StackIO(Structure):
+    _fields_ = [
+        ("B", c_int32), ("T", c_int32), ("Tk", c_int32), ("training", c_int32),
+        ("ids", c_void_p), ("type_ids", c_void_p), ("pos_ids", c_void_p),
+        ("key_mask", c_void_p), ("query_mask", c_void_p), ("mask3d", c_void_p),
+        ("causal", c_int32), ("reserved", c_int32),
+        ("enc_states", c_void_p), ("enc_mask", c_void_p),
+        ("out", c_void_p),
+        ("dropout_seed", c_uint64),
+        ("d_out", c_void_p), ("d_enc_states", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/imt_hip.h declares (tests/test_cabi.py checks)
 _P = c_void_p
 SIGNATURES = {
     "imt_version": (c_int, []),
     "imt_last_error": (c_char_p, []),
     "imt_gemm": (c_int, [POINTER(GemmArgs), _P]),
-    "imt_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, _P]),
+    "imt_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "imt_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, _P]),
     "imt_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, c_float,
                                   c_uint64, _P]),
@@ -79,6 +124,11 @@ SIGNATURES = {
                               c_int64, c_int, _P]),
     "imt_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
     "imt_gated_mix": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "imt_prof_enable": (c_int, [c_int]),
+    "imt_prof_report": (c_int, [POINTER(ProfRow), c_int]),
+    "imt_stack_workspace_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int, c_int]),
+    "imt_stack_forward": (c_int, [POINTER(StackDesc), POINTER(StackIO), _P, c_int64, _P]),
+    "imt_stack_backward": (c_int, [POINTER(StackDesc), POINTER(StackIO), _P, c_int64, c_int, c_int, _P]),
 }
 
 _lib = None

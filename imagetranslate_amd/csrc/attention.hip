@@ -409,18 +409,32 @@ AttnP make_params(const imt_attn_args* a) {
 
 template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
   dim3 grid(imt_cdiv(p.Tq, 64), p.H, p.B);
+  const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
+  const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
+  ImtProfScope prof(sizeof(T) == 2 ? "attn_fwd_bf16" : "attn_fwd_f32", 4.0 * work, io, st);
   hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, st, p);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
 template <typename T, int DH> int bwd_launch(const AttnP& p, hipStream_t st) {
   const int64_t total = (int64_t)p.B * p.Tq * p.H * (DH / 4);
-  hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3(imt_cdiv(total, 256)), dim3(256), 0, st, p);
-  IMT_CHECK_LAUNCH();
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64), p.H, p.B), dim3(256), 0, st, p);
-  IMT_CHECK_LAUNCH();
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH>), dim3(imt_cdiv(p.Tk, 64), p.H, p.B), dim3(256), 0, st, p);
-  IMT_CHECK_LAUNCH();
+  const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
+  const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
+  {
+    ImtProfScope prof("attn_bwd_delta", 0.0, (double)p.B * p.H * p.Tq * DH * sizeof(T) * 2.0, st);
+    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3(imt_cdiv(total, 256)), dim3(256), 0, st, p);
+    IMT_CHECK_LAUNCH();
+  }
+  {
+    ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dq_bf16" : "attn_bwd_dq_f32", 6.0 * work, io * 1.5, st);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64), p.H, p.B), dim3(256), 0, st, p);
+    IMT_CHECK_LAUNCH();
+  }
+  {
+    ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dkdv_bf16" : "attn_bwd_dkdv_f32", 8.0 * work, io * 1.5, st);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH>), dim3(imt_cdiv(p.Tk, 64), p.H, p.B), dim3(256), 0, st, p);
+    IMT_CHECK_LAUNCH();
+  }
   return IMT_OK;
 }
 

@@ -41,6 +41,17 @@ void imt_set_error(const char* fmt, ...);
 
 static inline int imt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------- optional launch profiler (core.hip)
+bool imt_prof_enabled();
+void* imt_prof_begin_launch(const char* kind, double flops, double bytes, hipStream_t st);
+void imt_prof_end_launch(void* tok, hipStream_t st);
+struct ImtProfScope {
+  void* tok; hipStream_t st;
+  ImtProfScope(const char* kind, double flops, double bytes, hipStream_t s)
+      : tok(imt_prof_enabled() ? imt_prof_begin_launch(kind, flops, bytes, s) : nullptr), st(s) {}
+  ~ImtProfScope() { if (tok) imt_prof_end_launch(tok, st); }
+};
+
 // ---------------------------------------------------------------- scalar conversions
 template <typename T> IMT_DEVICE float to_f32(T v);
 template <> IMT_DEVICE float to_f32<float>(float v) { return v; }

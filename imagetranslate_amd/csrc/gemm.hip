@@ -56,7 +56,7 @@ struct EpiParams {
   const void* bias; const void* resid; int64_t ldr;
   void* aux; int64_t ldaux; int aux_mode;
   int atomic;
-  float alpha;
+  float alpha; const float* alpha_dev;
   float inv_keep; uint32_t drop_thresh; uint64_t seed;
 };
 
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const T* __restrict__ A,
   }
 
   // ---------------------------------------------------------------- epilogue
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
   // lane owns C[m = m0+wm+16i+lr][n = n0+wn+16j+4lg .. +3]
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* resid = reinterpret_cast<const T*>(ep.resid);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const T* __restrict__ A,
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn + 16 * j + 4 * lg;
       if (n >= N) continue;
-      f32x4 v = acc[i][j] * ep.alpha;
+      f32x4 v = acc[i][j] * alpha;
       const bool full = (n + 3 < N);
       if (ep.atomic) {
         float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
@@ -225,6 +226,10 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_set = true;
   }
+  static const char* const kinds[2][3] = {{"gemm_f32_nt", "gemm_f32_nn", "gemm_f32_tn"}, {"gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn"}};
+  const double es = sizeof(T), esc = ep.c_f32 ? 4.0 : es;
+  ImtProfScope prof(kinds[sizeof(T) == 2][LAYOUT], 2.0 * a->M * a->N * a->K,
+                    ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * esc, st);
   hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), 65536, st, reinterpret_cast<const T*>(a->A), a->lda,
                      reinterpret_cast<const T*>(a->B), a->ldb, a->M, a->N, a->K, k_per_split, ep);
   IMT_CHECK_LAUNCH();
@@ -275,7 +280,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   ep.bias = a->bias; ep.resid = a->resid; ep.ldr = a->ldr;
   ep.aux = a->aux; ep.ldaux = a->ldaux; ep.aux_mode = a->aux_mode;
   ep.atomic = (splits > 1);
-  ep.alpha = a->alpha;
+  ep.alpha = a->alpha; ep.alpha_dev = a->alpha_dev;
   ep.drop_thresh = dropout_thresh(a->dropout_p);
   ep.inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
   ep.seed = a->dropout_seed;

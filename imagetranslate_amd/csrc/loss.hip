@@ -152,6 +152,7 @@ extern "C" int imt_log_softmax_fwd(int dtype, const void* logits, int64_t ld, fl
   if (N <= 0) return IMT_OK;
   IMT_CHECK_ARG(logits && lp && V > 0 && ld % 4 == 0 && ldlp % 4 == 0, "log_softmax_fwd: bad args");
   hipStream_t st = (hipStream_t)stream;
+  ImtProfScope prof("log_softmax_fwd", 0.0, (double)N * V * ((dtype == IMT_BF16 ? 2 : 4) + 4.0), st);
   if (dtype == IMT_F32)
     hipLaunchKernelGGL(log_softmax_fwd_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)logits, ld, lp, ldlp, lse, V);
   else
@@ -198,6 +199,7 @@ extern "C" int imt_xent_fused_fwd_bwd(int dtype, void* logits, int64_t ld, const
   if (N <= 0) return IMT_OK;
   IMT_CHECK_ARG(logits && target && loss_rows && V > 0 && ld % 4 == 0, "xent_fused: bad args");
   hipStream_t st = (hipStream_t)stream;
+  ImtProfScope prof("xent_fused", 0.0, 2.0 * N * V * (dtype == IMT_BF16 ? 2 : 4), st);
   if (dtype == IMT_F32)
     hipLaunchKernelGGL(xent_fused_kernel<float>, dim3(N), dim3(256), 0, st, (float*)logits, ld, target, loss_rows, V, epsilon, ignore_index, grad_scale);
   else

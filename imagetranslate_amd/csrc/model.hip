@@ -1,0 +1,349 @@
+// Host-side runtime: chains the kernels for a whole BERT encoder / cross-attending decoder stack
+// (BertEncoderModel.forward src/bert_seq2seq.py:103-144, BertDecoderModel.forward :40-91, with the HF-BERT
+// 2.9.0 layer semantics restated in SURVEY section 8: post-LN, erf-GELU, additive -10000 masks) and their
+// backward passes.  Pure enqueue: no allocation, no synchronisation; every launch goes to the caller's stream
+// so the whole forward/backward is capturable in a hipGraph.  Activations needed by backward are kept in the
+// caller-owned workspace, carved identically by forward and backward.
+#include "common.hpp"
+
+namespace {
+
+struct Carver {
+  char* base; int64_t off;
+  explicit Carver(void* b) : base(reinterpret_cast<char*>(b)), off(0) {}
+  void* take(int64_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += (bytes + 255) & ~(int64_t)255;
+    return p;
+  }
+};
+
+struct AttnWs {  // one attention block (self or cross)
+  void* qkv;     // self: [N,3d] ; cross: q [N,d] then kv [Nk,2d]
+  void* kv;      // cross only
+  void* ctx;     // [N,d]
+  float* lse;    // [B,H,T]
+  void* pre_ln;  // [N,d]  dense + residual (LN input)
+  float* mean; float* rstd;
+  void* out;     // [N,d]  LN output
+};
+struct LayerWs {
+  AttnWs self_attn, cross;
+  void* z; void* h;  // [N,ff]
+  void* pre_ln2; float* mean2; float* rstd2;
+  void* out;         // [N,d]
+};
+struct StackWs {
+  void* emb_sum; float* emb_mean; float* emb_rstd; void* x0;
+  LayerWs* layers;  // host array (carved on the stack of the caller)
+  // backward scratch
+  void* d_a; void* d_b; void* d_c;  // [N,d] each
+  void* d_ff;                        // [N,ff]
+  void* d_qkv;                       // [N,3d]
+  void* d_kv;                        // [Nk,2d]
+  float* delta;                      // [B,H,T]
+  int64_t bytes;
+};
+
+constexpr int MAX_LAYERS = 64;
+
+int64_t esize(int dtype) { return dtype == IMT_BF16 ? 2 : 4; }
+
+void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, LayerWs* layers) {
+  Carver c(ws);
+  const int64_t N = (int64_t)B * T, Nk = (int64_t)B * Tk, d = m->d, ff = m->ff, es = esize(m->dtype);
+  w.emb_sum = c.take(N * d * es); w.emb_mean = (float*)c.take(N * 4); w.emb_rstd = (float*)c.take(N * 4);
+  w.x0 = c.take(N * d * es);
+  w.layers = layers;
+  for (int l = 0; l < m->n_layers; ++l) {
+    LayerWs& L = layers[l];
+    AttnWs& s = L.self_attn;
+    s.qkv = c.take(N * 3 * d * es); s.kv = nullptr; s.ctx = c.take(N * d * es);
+    s.lse = (float*)c.take((int64_t)B * m->heads * T * 4);
+    s.pre_ln = c.take(N * d * es); s.mean = (float*)c.take(N * 4); s.rstd = (float*)c.take(N * 4);
+    s.out = c.take(N * d * es);
+    AttnWs& x = L.cross;
+    memset(&x, 0, sizeof(x));
+    if (m->is_decoder && m->layers[l].cross_attn.qkv_w >= 0) {
+      x.qkv = c.take(N * d * es); x.kv = c.take(Nk * 2 * d * es); x.ctx = c.take(N * d * es);
+      x.lse = (float*)c.take((int64_t)B * m->heads * T * 4);
+      x.pre_ln = c.take(N * d * es); x.mean = (float*)c.take(N * 4); x.rstd = (float*)c.take(N * 4);
+      x.out = c.take(N * d * es);
+    }
+    L.z = c.take(N * ff * es); L.h = c.take(N * ff * es);
+    L.pre_ln2 = c.take(N * d * es); L.mean2 = (float*)c.take(N * 4); L.rstd2 = (float*)c.take(N * 4);
+    L.out = c.take(N * d * es);
+  }
+  w.d_a = c.take(N * d * es); w.d_b = c.take(N * d * es); w.d_c = c.take(N * d * es);
+  w.d_ff = c.take(N * ff * es);
+  w.d_qkv = c.take(N * 3 * d * es);
+  w.d_kv = c.take((Nk > 0 ? Nk : 1) * 2 * d * es);
+  w.delta = (float*)c.take((int64_t)B * m->heads * T * 4);
+  w.bytes = c.off;
+}
+
+struct Ctx {
+  const imt_stack_desc* m; hipStream_t st; int dtype; int64_t es;
+  const char* P(int64_t off) const { return reinterpret_cast<const char*>(m->params) + off * es; }
+  float* G(int64_t off) const { return m->grads + off; }
+};
+
+#define RC(x) do { int rc__ = (x); if (rc__ != IMT_OK) return rc__; } while (0)
+
+// y[M,N] = epilogue(x[M,K] W[N,K]^T)
+int linear_fwd(const Ctx& c, const void* x, int64_t ldx, int M, int K, int64_t w_off, int64_t b_off, int N, void* y, int64_t ldy,
+               const void* resid, int64_t ldr, void* aux, int aux_mode, float drop_p, uint64_t seed) {
+  imt_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = c.dtype; a.layout = IMT_NT; a.M = M; a.N = N; a.K = K;
+  a.A = x; a.lda = ldx; a.B = c.P(w_off); a.ldb = K; a.C = y; a.ldc = ldy; a.c_dtype = c.dtype;
+  a.bias = b_off >= 0 ? c.P(b_off) : nullptr;
+  a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = N; a.aux_mode = aux_mode; a.split_k = 1; a.alpha = 1.f;
+  a.dropout_p = drop_p; a.dropout_seed = seed;
+  return imt_gemm(&a, c.st);
+}
+
+// dx[M,K] = epilogue(dy[M,N] W[N,K])        (W stored [N,K] row-major -> NN with B = W)
+int linear_bwd_input(const Ctx& c, const void* dy, int64_t lddy, int M, int N, int64_t w_off, int K, void* dx, int64_t lddx,
+                     const void* resid, int64_t ldr, void* aux, int aux_mode, int accumulate) {
+  imt_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = c.dtype; a.layout = IMT_NN; a.M = M; a.N = K; a.K = N;
+  a.A = dy; a.lda = lddy; a.B = c.P(w_off); a.ldb = K; a.C = dx; a.ldc = lddx; a.c_dtype = c.dtype;
+  a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = K; a.aux_mode = aux_mode; a.split_k = 1; a.alpha = 1.f;
+  a.accumulate = accumulate;
+  return imt_gemm(&a, c.st);
+}
+
+int pick_split_k(int M, int N, int K) {
+  // enough workgroups to cover the 256 CUs about twice, but keep each split >= 256 deep
+  const int tiles = imt_cdiv(M, 128) * imt_cdiv(N, 128);
+  int s = 512 / (tiles > 0 ? tiles : 1);
+  const int smax = K / 256;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+// dW[N,K] += dy[M,N]^T x[M,K] ; db[N] += colsum(dy)
+int linear_bwd_params(const Ctx& c, const void* dy, int64_t lddy, const void* x, int64_t ldx, int M, int N, int K, int64_t w_off,
+                      int64_t b_off) {
+  imt_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = c.dtype; a.layout = IMT_TN; a.M = N; a.N = K; a.K = M;
+  a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = c.G(w_off); a.ldc = K; a.c_dtype = IMT_F32; a.alpha = 1.f;
+  a.split_k = pick_split_k(N, K, M);
+  a.accumulate = (a.split_k == 1);
+  RC(imt_gemm(&a, c.st));
+  if (b_off >= 0) RC(imt_colsum(c.dtype, dy, lddy, M, N, c.G(b_off), nullptr, c.st));
+  return IMT_OK;
+}
+
+uint64_t site_seed(uint64_t base, int layer, int site) { return base + 0x9E3779B97F4A7C15ull * (uint64_t)(layer * 16 + site + 1); }
+
+struct MaskSet { const uint8_t* key; const uint8_t* query; const uint8_t* m3d; int causal; };
+
+int attn_args(const Ctx& c, imt_attn_args& a, int B, int Tq, int Tk, const void* q, int64_t ldq, const void* k, int64_t ldk,
+              const void* v, int64_t ldv, void* o, float* lse, const MaskSet& ms, float drop_p, uint64_t seed) {
+  memset(&a, 0, sizeof(a));
+  a.dtype = c.dtype; a.B = B; a.H = c.m->heads; a.Tq = Tq; a.Tk = Tk; a.head_dim = c.m->d / c.m->heads;
+  a.Q = q; a.ldq = ldq; a.K = k; a.ldk = ldk; a.V = v; a.ldv = ldv; a.O = o; a.ldo = c.m->d; a.lse = lse;
+  a.key_mask = ms.key; a.query_mask = ms.query; a.mask3d = ms.m3d; a.causal = ms.causal;
+  a.scale = 1.0f / sqrtf((float)a.head_dim);
+  a.dropout_p = drop_p; a.dropout_seed = seed;
+  return IMT_OK;
+}
+
+inline const char* offp(const void* p, int64_t elems, int64_t es) { return reinterpret_cast<const char*>(p) + elems * es; }
+inline char* offp(void* p, int64_t elems, int64_t es) { return reinterpret_cast<char*>(p) + elems * es; }
+
+// ------------------------------------------------------------------------------------------------ forward
+// attention block (BertAttention = BertSelfAttention + BertSelfOutput); kv_src == nullptr -> self attention
+int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void* x, int B, int T, const void* kv_src, int Tk,
+                   const MaskSet& ms, bool training, uint64_t seed, int layer, int site0) {
+  const int d = c.m->d;
+  const int N = B * T;
+  const float hp = training ? c.m->hidden_dropout : 0.f, ap = training ? c.m->attn_dropout : 0.f;
+  imt_attn_args a;
+  if (!kv_src) {
+    RC(linear_fwd(c, x, d, N, d, p.qkv_w, p.qkv_b, 3 * d, w.qkv, 3 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    attn_args(c, a, B, T, T, w.qkv, 3 * d, offp(w.qkv, d, c.es), 3 * d, offp(w.qkv, 2 * d, c.es), 3 * d, w.ctx, w.lse, ms, ap,
+              site_seed(seed, layer, site0));
+  } else {
+    const int Nk = B * Tk;
+    RC(linear_fwd(c, x, d, N, d, p.qkv_w, p.qkv_b, d, w.qkv, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    RC(linear_fwd(c, kv_src, d, Nk, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d, 2 * d, w.kv, 2 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, 2 * d, offp(w.kv, d, c.es), 2 * d, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
+  }
+  RC(imt_attention_fwd(&a, c.st));
+  RC(linear_fwd(c, w.ctx, d, N, d, p.o_w, p.o_b, d, w.pre_ln, d, x, d, nullptr, IMT_AUX_NONE, hp, site_seed(seed, layer, site0 + 1)));
+  RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.ln_g), c.P(p.ln_b), w.out, w.mean, w.rstd, N, d, c.m->ln_eps, 0.f, 0, c.st));
+  return IMT_OK;
+}
+
+// backward of the block: dy = grad of w.out ; writes dx (grad of x) ; cross: also d_kv_src (accumulate flag)
+int attn_block_bwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, StackWs& sw, const void* x, int B, int T, const void* kv_src,
+                   int Tk, const MaskSet& ms, bool training, uint64_t seed, int layer, int site0, const void* dy, void* dx,
+                   void* d_kv_src, int accumulate_kv) {
+  const int d = c.m->d;
+  const int N = B * T;
+  const float hp = training ? c.m->hidden_dropout : 0.f, ap = training ? c.m->attn_dropout : 0.f;
+  // LN backward: d_pre (residual path) in sw.d_b ; dropped copy for the dense path in sw.d_c when dropout is on
+  void* d_pre = sw.d_b;
+  void* d_dense = (hp > 0.f) ? sw.d_c : d_pre;
+  RC(imt_layernorm_bwd(c.dtype, dy, w.pre_ln, c.P(p.ln_g), w.mean, w.rstd, d_pre, c.G(p.ln_g), c.G(p.ln_b), N, d, 0.f, 0,
+                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, site0 + 1), c.st));
+  RC(linear_bwd_params(c, d_dense, d, w.ctx, d, N, d, d, p.o_w, p.o_b));
+  // d_ctx -> reuse sw.d_c if free, else sw.d_a (dy may alias d_a: dy is dead after the LN backward above)
+  void* d_ctx = (hp > 0.f) ? sw.d_a : sw.d_c;
+  RC(linear_bwd_input(c, d_dense, d, N, d, p.o_w, d, d_ctx, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0));
+  imt_attn_args a;
+  if (!kv_src) {
+    attn_args(c, a, B, T, T, w.qkv, 3 * d, offp(w.qkv, d, c.es), 3 * d, offp(w.qkv, 2 * d, c.es), 3 * d, w.ctx, w.lse, ms, ap,
+              site_seed(seed, layer, site0));
+    a.dO = d_ctx; a.lddo = d;
+    a.dQ = sw.d_qkv; a.lddq = 3 * d; a.dK = offp(sw.d_qkv, d, c.es); a.lddk = 3 * d; a.dV = offp(sw.d_qkv, 2 * d, c.es); a.lddv = 3 * d;
+    a.delta = sw.delta;
+    RC(imt_attention_bwd(&a, c.st));
+    RC(linear_bwd_params(c, sw.d_qkv, 3 * d, x, d, N, 3 * d, d, p.qkv_w, p.qkv_b));
+    RC(linear_bwd_input(c, sw.d_qkv, 3 * d, N, 3 * d, p.qkv_w, d, dx, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
+  } else {
+    const int Nk = B * Tk;
+    attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, 2 * d, offp(w.kv, d, c.es), 2 * d, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
+    a.dO = d_ctx; a.lddo = d;
+    a.dQ = sw.d_qkv; a.lddq = d; a.dK = sw.d_kv; a.lddk = 2 * d; a.dV = offp(sw.d_kv, d, c.es); a.lddv = 2 * d;
+    a.delta = sw.delta;
+    RC(imt_attention_bwd(&a, c.st));
+    RC(linear_bwd_params(c, sw.d_qkv, d, x, d, N, d, d, p.qkv_w, p.qkv_b));
+    RC(linear_bwd_params(c, sw.d_kv, 2 * d, kv_src, d, Nk, 2 * d, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d));
+    RC(linear_bwd_input(c, sw.d_qkv, d, N, d, p.qkv_w, d, dx, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
+    if (d_kv_src)
+      RC(linear_bwd_input(c, sw.d_kv, 2 * d, Nk, 2 * d, p.qkv_w + (int64_t)d * d, d, d_kv_src, d, nullptr, 0, nullptr, IMT_AUX_NONE, accumulate_kv));
+  }
+  return IMT_OK;
+}
+
+int ffn_fwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, const void* x, int N, bool training, uint64_t seed, int layer) {
+  const int d = c.m->d, ff = c.m->ff;
+  const float hp = training ? c.m->hidden_dropout : 0.f;
+  RC(linear_fwd(c, x, d, N, d, p.ff1_w, p.ff1_b, ff, w.h, ff, nullptr, 0, w.z, IMT_AUX_GELU_FWD, 0.f, 0));
+  RC(linear_fwd(c, w.h, ff, N, ff, p.ff2_w, p.ff2_b, d, w.pre_ln2, d, x, d, nullptr, IMT_AUX_NONE, hp, site_seed(seed, layer, 8)));
+  RC(imt_layernorm_fwd(c.dtype, w.pre_ln2, c.P(p.ln2_g), c.P(p.ln2_b), w.out, w.mean2, w.rstd2, N, d, c.m->ln_eps, 0.f, 0, c.st));
+  return IMT_OK;
+}
+
+int ffn_bwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, StackWs& sw, const void* x, int N, bool training, uint64_t seed, int layer,
+            const void* dy, void* dx) {
+  const int d = c.m->d, ff = c.m->ff;
+  const float hp = training ? c.m->hidden_dropout : 0.f;
+  void* d_pre = sw.d_b;
+  void* d_dense = (hp > 0.f) ? sw.d_c : d_pre;
+  RC(imt_layernorm_bwd(c.dtype, dy, w.pre_ln2, c.P(p.ln2_g), w.mean2, w.rstd2, d_pre, c.G(p.ln2_g), c.G(p.ln2_b), N, d, 0.f, 0,
+                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, 8), c.st));
+  RC(linear_bwd_params(c, d_dense, d, w.h, ff, N, d, ff, p.ff2_w, p.ff2_b));
+  RC(linear_bwd_input(c, d_dense, d, N, d, p.ff2_w, ff, sw.d_ff, ff, nullptr, 0, w.z, IMT_AUX_DGELU, 0));  // dz
+  RC(linear_bwd_params(c, sw.d_ff, ff, x, d, N, ff, d, p.ff1_w, p.ff1_b));
+  RC(linear_bwd_input(c, sw.d_ff, ff, N, ff, p.ff1_w, d, dx, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
+  return IMT_OK;
+}
+
+int validate(const imt_stack_desc* m, const imt_stack_io* io, const void* ws, int64_t ws_bytes, StackWs& w, LayerWs* layers) {
+  IMT_CHECK_ARG(m && io, "stack: null descriptor");
+  IMT_CHECK_ARG(m->dtype == IMT_F32 || m->dtype == IMT_BF16, "stack: bad dtype");
+  IMT_CHECK_ARG(m->n_layers >= 0 && m->n_layers <= MAX_LAYERS && (m->n_layers == 0 || m->layers), "stack: bad layer table");
+  IMT_CHECK_ARG(m->d > 0 && m->heads > 0 && m->d % m->heads == 0, "stack: hidden size %d not a multiple of heads %d", m->d, m->heads);
+  const int dh = m->d / m->heads;
+  IMT_CHECK_ARG(dh == 32 || dh == 64, "stack: head_dim %d unsupported (32 or 64)", dh);
+  IMT_CHECK_ARG(m->d % 8 == 0 && m->ff % 8 == 0, "stack: d and ff must be multiples of 8");
+  IMT_CHECK_ARG(io->B > 0 && io->T > 0, "stack: empty batch");
+  IMT_CHECK_ARG(io->T <= m->max_pos || io->pos_ids, "stack: sequence longer than max_position_embeddings");
+  IMT_CHECK_ARG(m->params && io->ids && io->out, "stack: null tensor");
+  if (m->is_decoder) IMT_CHECK_ARG(io->enc_states && io->Tk > 0, "stack: decoder needs encoder states");
+  carve(m, io->B, io->T, m->is_decoder ? io->Tk : 0, const_cast<void*>(ws), w, layers);
+  IMT_CHECK_ARG(ws && ws_bytes >= w.bytes, "stack: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
+  IMT_CHECK_ARG(((uintptr_t)ws & 255) == 0, "stack: workspace must be 256-B aligned");
+  return IMT_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t imt_stack_workspace_bytes(const imt_stack_desc* m, int B, int T, int Tk) {
+  if (!m || m->n_layers > MAX_LAYERS || (m->n_layers > 0 && !m->layers)) return -1;
+  StackWs w; LayerWs layers[MAX_LAYERS];
+  carve(m, B, T, m->is_decoder ? Tk : 0, nullptr, w, layers);
+  return w.bytes;
+}
+
+extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, void* stream) {
+  StackWs w; LayerWs layers[MAX_LAYERS];
+  RC(validate(m, io, ws, ws_bytes, w, layers));
+  Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  const int B = io->B, T = io->T, N = B * T, d = m->d;
+  const bool training = io->training != 0;
+  const uint64_t seed = io->dropout_seed;
+  RC(imt_embed_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), w.emb_sum, N, T, d,
+                   m->vocab, m->max_pos, m->n_types, c.st));
+  void* x0 = (m->n_layers == 0) ? io->out : w.x0;
+  RC(imt_layernorm_fwd(c.dtype, w.emb_sum, c.P(m->emb_ln_g), c.P(m->emb_ln_b), x0, w.emb_mean, w.emb_rstd, N, d, m->ln_eps,
+                       training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), c.st));
+  const void* x = x0;
+  const MaskSet self_ms{io->key_mask, io->query_mask, io->mask3d, io->causal};
+  const MaskSet cross_ms{io->enc_mask, nullptr, nullptr, 0};
+  for (int l = 0; l < m->n_layers; ++l) {
+    const imt_layer_desc& p = m->layers[l];
+    LayerWs& L = layers[l];
+    RC(attn_block_fwd(c, p.self_attn, L.self_attn, x, B, T, nullptr, 0, self_ms, training, seed, l, 0));
+    const void* a = L.self_attn.out;
+    if (m->is_decoder && p.cross_attn.qkv_w >= 0) {
+      RC(attn_block_fwd(c, p.cross_attn, L.cross, a, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4));
+      a = L.cross.out;
+    }
+    if (l == m->n_layers - 1) L.out = io->out;  // last LN writes straight into the caller's output
+    RC(ffn_fwd(c, p, L, a, N, training, seed, l));
+    x = L.out;
+  }
+  return IMT_OK;
+}
+
+extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, int layer_lo,
+                                  int layer_hi, void* stream) {
+  StackWs w; LayerWs layers[MAX_LAYERS];
+  RC(validate(m, io, ws, ws_bytes, w, layers));
+  IMT_CHECK_ARG(m->grads && io->d_out, "stack_backward: grads / d_out missing");
+  IMT_CHECK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= m->n_layers, "stack_backward: bad layer range");
+  Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  const int B = io->B, T = io->T, N = B * T, d = m->d;
+  const bool training = io->training != 0;
+  const uint64_t seed = io->dropout_seed;
+  const MaskSet self_ms{io->key_mask, io->query_mask, io->mask3d, io->causal};
+  const MaskSet cross_ms{io->enc_mask, nullptr, nullptr, 0};
+  // The running gradient w.r.t. the current layer's output lives in w.d_a between layers (and between
+  // segment calls); the first segment reads it from io->d_out.
+  const void* dy = (layer_hi == m->n_layers) ? io->d_out : w.d_a;
+  for (int l = layer_hi - 1; l >= layer_lo; --l) {
+    const imt_layer_desc& p = m->layers[l];
+    LayerWs& L = layers[l];
+    if (l == m->n_layers - 1) L.out = io->out;
+    const bool has_cross = m->is_decoder && p.cross_attn.qkv_w >= 0;
+    const void* x_in = (l == 0) ? w.x0 : (const void*)layers[l - 1].out;
+    const void* a_self = L.self_attn.out;
+    const void* a_ffn_in = has_cross ? L.cross.out : a_self;
+    RC(ffn_bwd(c, p, L, w, a_ffn_in, N, training, seed, l, dy, w.d_a));
+    if (has_cross) {
+      const bool first_cross = (l == m->n_layers - 1);
+      RC(attn_block_bwd(c, p.cross_attn, L.cross, w, a_self, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4, w.d_a, w.d_a,
+                        io->d_enc_states, first_cross ? 0 : 1));
+    }
+    RC(attn_block_bwd(c, p.self_attn, L.self_attn, w, x_in, B, T, nullptr, 0, self_ms, training, seed, l, 0, w.d_a, w.d_a, nullptr, 0));
+    dy = w.d_a;
+  }
+  if (layer_lo == 0) {
+    const void* dy0 = (m->n_layers == 0) ? io->d_out : dy;
+    RC(imt_layernorm_bwd(c.dtype, dy0, w.emb_sum, c.P(m->emb_ln_g), w.emb_mean, w.emb_rstd, w.d_b, c.G(m->emb_ln_g), c.G(m->emb_ln_b), N, d,
+                         training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), nullptr, 0.f, 0, c.st));
+    RC(imt_embed_bwd(c.dtype, io->ids, io->pos_ids, io->type_ids, w.d_b, c.G(m->emb_word), c.G(m->emb_pos), c.G(m->emb_type), N, T, d,
+                     m->pad_id, c.st));
+  }
+  return IMT_OK;
+}

@@ -80,6 +80,7 @@ extern "C" int imt_sumsq(const float* g, int64_t n, float* out, void* stream) {
   int blocks = imt_cdiv(n, 4096);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
+  ImtProfScope prof("grad_sumsq", 0.0, 4.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
@@ -100,6 +101,7 @@ extern "C" int imt_clip_adam(float* p, float* g, float* m, float* v, void* p_bf1
   int blocks = imt_cdiv(n, 2048);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
+  ImtProfScope prof("clip_adam", 0.0, (p_bf16 ? 34.0 : 32.0) * n, (hipStream_t)stream);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, sumsq, a);
   IMT_CHECK_LAUNCH();
   return IMT_OK;

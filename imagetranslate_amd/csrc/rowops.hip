@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 // ------------------------------------------------------------------------------------------- column sums
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ldx, int M, int N,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, int rows_per_block,
+                                                     const float* __restrict__ scale_dev) {
   __shared__ f32x4 red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
   __syncthreads();
   if (w == 0 && c < N) {
     f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (scale_dev) s *= scale_dev[0];
     for (int e = 0; e < 4 && c + e < N; ++e) atomicAdd(out + c + e, s[e]);
   }
 }
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256) void gated_mix_kernel(const T* __restrict__ a,
 template <typename T, int NCH>
 int ln_fwd_launch(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int rows, int d,
                   float eps, float p, uint64_t seed, hipStream_t st) {
+  ImtProfScope prof("layernorm_fwd", 0.0, 2.0 * rows * d * sizeof(T), st);
   hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(imt_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, st,
                      (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd, rows, d, eps, dropout_thresh(p),
                      p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
@@ -291,6 +294,7 @@ int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float*
   int rpw = imt_cdiv(rows, 512 * ROWS_PER_BLOCK);
   if (rpw < 1) rpw = 1;
   const int blocks = imt_cdiv(rows, rpw * ROWS_PER_BLOCK);
+  ImtProfScope prof("layernorm_bwd", 0.0, (dx_drop ? 4.0 : 3.0) * rows * d * sizeof(T), st);
   hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
                      (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),
                      yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),
@@ -349,6 +353,7 @@ extern "C" int imt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_i
   IMT_CHECK_ARG(ids && word && pos && type && out, "embed_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(imt_cdiv(n_tokens, ROWS_PER_BLOCK));
+  ImtProfScope prof("embed_fwd", 0.0, 4.0 * n_tokens * d * (dtype == IMT_BF16 ? 2 : 4), st);
   if (dtype == IMT_F32)
     hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const float*)word,
                        (const float*)pos, (const float*)type, (float*)out, n_tokens, seq_len, d, vocab, max_pos, n_types);
@@ -369,6 +374,7 @@ extern "C" int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_i
   hipStream_t st = (hipStream_t)stream;
   const int tokb = 16;
   dim3 grid(imt_cdiv(n_tokens, tokb));
+  ImtProfScope prof("embed_bwd", 0.0, (double)n_tokens * d * ((dtype == IMT_BF16 ? 2 : 4) + 16.0), st);
   if (dtype == IMT_F32)
     hipLaunchKernelGGL((embed_bwd_kernel<float, 4>), grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const float*)dsum,
                        dword, dpos, dtype_tab, n_tokens, seq_len, d, pad_id, tokb);
@@ -379,17 +385,19 @@ extern "C" int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_i
   return IMT_OK;
 }
 
-extern "C" int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, void* stream) {
+extern "C" int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, const float* scale_dev,
+                          void* stream) {
   IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "colsum: bad dtype");
   if (M <= 0 || N <= 0) return IMT_OK;
   IMT_CHECK_ARG(X && out && ldx % 4 == 0, "colsum: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int rpb = 64;
   dim3 grid(imt_cdiv(N, 256), imt_cdiv(M, rpb));
+  ImtProfScope prof("colsum", 0.0, (double)M * N * (dtype == IMT_BF16 ? 2 : 4), st);
   if (dtype == IMT_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ldx, M, N, out, rpb);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ldx, M, N, out, rpb, scale_dev);
   else
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, ldx, M, N, out, rpb);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, ldx, M, N, out, rpb, scale_dev);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
@@ -402,6 +410,7 @@ static int gather_scatter(int dtype, const void* x, int64_t ldx, const int32_t* 
   IMT_CHECK_ARG(x && idx && out, "gather_rows: null pointer");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(imt_cdiv(n_sel, ROWS_PER_BLOCK));
+  ImtProfScope prof(scatter ? "scatter_rows" : "gather_rows", 0.0, 2.0 * n_sel * d * (dtype == IMT_BF16 ? 2 : 4), st);
   if (dtype == IMT_F32)
     hipLaunchKernelGGL(gather_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, idx, (float*)out, ldo, n_sel, d, scatter);
   else
@@ -424,6 +433,7 @@ extern "C" int imt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void
   IMT_CHECK_ARG(src && dst, "cast: null pointer");
   int blocks = imt_cdiv(n, 1024);
   if (blocks > 2048) blocks = 2048;
+  ImtProfScope prof("cast_f32_to_bf16", 0.0, 6.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
   IMT_CHECK_LAUNCH();
   return IMT_OK;

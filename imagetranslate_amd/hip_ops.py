@@ -39,7 +39,7 @@ def _rowmajor(t):
 
 
 def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=None, aux_mode=IMT_AUX_NONE,
-         accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0):
+         accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0, alpha_dev=None):
     """C = epilogue(op(A) op(B)); see include/imt_hip.h:imt_gemm."""
     _req_cuda(A, B, out, bias, resid, aux)
     if layout == IMT_NT:
@@ -64,13 +64,15 @@ def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=N
     a.aux, a.ldaux = (aux.data_ptr(), _rowmajor(aux)) if aux is not None else (None, 0)
     a.aux_mode, a.split_k = aux_mode, split_k
     a.alpha, a.dropout_p, a.dropout_seed = alpha, dropout_p, dropout_seed
+    a.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
     L.check(L.load().imt_gemm(ctypes.byref(a), _stream()), "imt_gemm")
     return out
 
 
-def colsum(X, out):
+def colsum(X, out, scale_dev=None):
     _req_cuda(X, out)
-    L.check(L.load().imt_colsum(dt(X), _p(X), _rowmajor(X), X.shape[0], X.shape[1], _p(out), _stream()), "imt_colsum")
+    L.check(L.load().imt_colsum(dt(X), _p(X), _rowmajor(X), X.shape[0], X.shape[1], _p(out), _p(scale_dev), _stream()),
+            "imt_colsum")
     return out
 
 

@@ -1,0 +1,179 @@
+"""Flat parameter store: every unique parameter of a model lives in ONE fp32 master buffer (plus one fp32
+gradient buffer with the same offsets, Adam moments and an optional bf16 shadow copy).  The nn.Parameters that
+the reference's callers and checkpoints see (``encoder.encoder.layer.0.attention.self.query.weight`` ...) are
+VIEWS into that buffer, so
+
+  * the C runtime addresses parameters/gradients by element offset (include/imt_hip.h: imt_stack_desc),
+  * q|k|v projections are contiguous and run as one GEMM,
+  * grad-norm / Adam / the bf16 shadow / the RCCL all-reduce are single passes over contiguous memory,
+  * ``state_dict()`` / ``load_state_dict()`` keep the reference's key names and shapes.
+
+Layout is HBM-friendly: each tensor starts on a 256-byte boundary; the order is the order in which gradients
+become final during backward (output layers, decoder top->bottom, encoder top->bottom, embeddings) so that
+all-reduce buckets are contiguous ranges.
+"""
+import weakref
+from typing import List
+
+import torch
+import torch.nn as nn
+
+ALIGN = 64  # elements (256 B in fp32, 128 B in bf16)
+
+
+class FlatParams:
+    def __init__(self, root: nn.Module):
+        self._root = weakref.ref(root)
+        self.flat = None       # fp32 master [total]
+        self.grad = None       # fp32 grads  [total]
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self._shadow = None    # bf16 copy
+        self._shadow_version = -1
+        self._shadow_stale = True
+        self.entries = []      # (param, offset, numel)
+        self.index = {}        # id(param) -> offset
+        self.total = 0
+        self.layout_version = 0
+
+    # ------------------------------------------------------------------ layout
+    def _ordered_params(self) -> List[nn.Parameter]:
+        root = self._root()
+        order = root.flat_param_order() if hasattr(root, "flat_param_order") else []
+        seen, out = set(), []
+        for p in list(order) + list(root.parameters()):
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def valid(self) -> bool:
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        for p, off, n in self.entries:
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                return False
+        root = self._root()
+        if root is not None and sum(1 for _ in root.parameters()) != len(self.entries):
+            return False
+        return True
+
+    def ensure(self):
+        if not self.valid():
+            self.rebuild()
+        return self
+
+    def rebuild(self):
+        params = self._ordered_params()
+        if not params:
+            raise RuntimeError("FlatParams: model has no parameters")
+        device = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(total, dtype=torch.float32, device=device)
+        entries, index = [], {}
+        with torch.no_grad():
+            for p, off in zip(params, offs):
+                n = p.numel()
+                view = flat[off:off + n].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                gview = grad[off:off + n].view(p.shape)
+                if p.grad is not None:
+                    gview.copy_(p.grad.to(device=device, dtype=torch.float32))
+                p.data = view
+                p.grad = gview
+                p._imt_store = weakref.ref(self)
+                entries.append((p, off, n))
+                index[id(p)] = off
+        # carry optimizer moments across a rebuild when the set of parameters is unchanged
+        old_m, old_v, old_index = self.exp_avg, self.exp_avg_sq, dict(self.index)
+        self.flat, self.grad, self.entries, self.index, self.total = flat, grad, entries, index, total
+        self.exp_avg = self.exp_avg_sq = None
+        if old_m is not None and set(old_index) == set(index):
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+            for p, off, n in entries:
+                o = old_index[id(p)]
+                self.exp_avg[off:off + n].copy_(old_m[o:o + n])
+                self.exp_avg_sq[off:off + n].copy_(old_v[o:o + n])
+        self._shadow = None
+        self._shadow_stale = True
+        self.layout_version += 1
+
+    def offset(self, p: nn.Parameter) -> int:
+        return self.index[id(p)]
+
+    # ------------------------------------------------------------------ views used by the runtime
+    def attach_grad_views(self):
+        for p, off, n in self.entries:
+            g = p.grad
+            if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + n].view(p.shape)
+
+    def zero_grad(self):
+        if self.grad is not None:
+            self.grad.zero_()
+
+    def mark_master_changed(self):
+        self._shadow_stale = True
+
+    def params_for(self, dtype: torch.dtype) -> torch.Tensor:
+        """Flat parameter buffer in the compute dtype (fp32 master itself, or the bf16 shadow, refreshed when the
+        master changed through torch in-place ops or a fused optimizer step without shadow write)."""
+        if dtype == torch.float32:
+            return self.flat
+        assert dtype == torch.bfloat16
+        v = self._version_stamp()
+        if self._shadow is None or self._shadow_stale or v != self._shadow_version:
+            from . import hip_ops as O
+            if self._shadow is None:
+                self._shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat.device)
+            O.cast_f32_to_bf16(self.flat, self._shadow)
+            self._shadow_version = v
+            self._shadow_stale = False
+        return self._shadow
+
+    def shadow_buffer_for_optimizer(self):
+        """bf16 shadow the fused Adam kernel should write in the same pass (None if no bf16 consumer yet)."""
+        return self._shadow
+
+    def _version_stamp(self) -> int:
+        # in-place torch ops on a parameter view (load_state_dict, torch optimizers) bump that parameter's
+        # version counter (not the flat buffer's); the sum is a cheap "master changed behind our back" stamp.
+        return sum(p._version for p, _, _ in self.entries)
+
+    def note_shadow_written_by_optimizer(self):
+        self._shadow_version = self._version_stamp()
+        self._shadow_stale = False
+
+    def anchor(self) -> torch.Tensor:
+        """A 1-element leaf that requires grad: passing it into the stack autograd.Functions makes autograd
+        schedule their backward even though the real parameter gradients are written by the kernels."""
+        a = self.__dict__.get("_anchor")
+        if a is None or a.device != self.flat.device:
+            a = torch.zeros(1, device=self.flat.device, requires_grad=True)
+            self.__dict__["_anchor"] = a
+        return a
+
+    def moments(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.flat)
+            self.exp_avg_sq = torch.zeros_like(self.flat)
+        return self.exp_avg, self.exp_avg_sq
+
+
+def store_of(module: nn.Module) -> FlatParams:
+    """The flat store of the top-level model a stack module belongs to (created on first use)."""
+    owner = getattr(module, "_imt_owner", None)
+    root = owner() if owner is not None else None
+    if root is None:
+        root = module
+    st = root.__dict__.get("_imt_flat_store")
+    if st is None:
+        st = FlatParams(root)
+        root.__dict__["_imt_flat_store"] = st
+    return st

@@ -1,0 +1,195 @@
+"""Trainer-side pieces of the path -- drop-in for the parts of the reference's ``src/utils.py`` that sit inside the
+timed train step: ``build_optimizer`` (:14-16), ``AdamInverseSqrtWithWarmup`` (:105-156), gradient clipping
+(``train_image_mt.py:291``), plus ``mass_mask`` / ``mass_unmask`` (:41-82, host-side batch construction, kept on the
+host exactly as the reference) and ``backward`` (:85-90).
+
+The optimizer works on the model's FLAT buffers: global grad-norm = one reduction kernel, clip + Adam + bf16 shadow
+write + grad zeroing = one elementwise kernel (``imt_sumsq`` / ``imt_clip_adam``).
+"""
+import math
+import random
+from typing import Dict
+
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+from . import hip_ops as O
+
+
+def build_optimizer(model, learning_rate, warump_steps):
+    return AdamInverseSqrtWithWarmup(model.parameters(), lr=learning_rate, betas=(0.9, 0.98),
+                                     warmup_updates=warump_steps)
+
+
+def backward(loss, optimizer=None, fp16: bool = False):
+    # bf16 keeps fp32's exponent range: no loss scaling (the reference needs apex amp.scale_loss for fp16, :85-90)
+    loss.backward()
+
+
+class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
+    """Adam whose lr follows linear warm-up then inverse-sqrt decay, updated AFTER each step (src/utils.py:105-156).
+
+    ``step(max_grad_norm=..., grad_scale=...)`` additionally fuses ``clip_grad_norm_`` (and the 1/world_size of
+    data-parallel averaging) into the same kernel; plain ``step()`` after an external
+    ``torch.nn.utils.clip_grad_norm_`` (the reference's call sequence) gives the same result.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, warmup_updates=4000,
+                 warmup_init_lr=1e-7):
+        if weight_decay != 0:
+            raise ValueError("weight_decay is not used by the reference (src/utils.py:14-16) and not supported")
+        defaults = dict(lr=warmup_init_lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.warmup_updates = warmup_updates
+        self.warmup_init_lr = warmup_init_lr
+        warmup_end_lr = lr
+        self.lr_step = (warmup_end_lr - warmup_init_lr) / warmup_updates
+        self.decay_factor = warmup_end_lr * warmup_updates ** 0.5
+        for param_group in self.param_groups:
+            param_group['num_updates'] = 0
+        self.max_lr = lr
+        self._sumsq = None
+        self.last_grad_norm_sq = None  # device tensor of the last fused grad-norm^2 (no host sync)
+
+    def get_lr_for_step(self, num_updates):
+        if num_updates < self.warmup_updates:
+            return self.warmup_init_lr + num_updates * self.lr_step
+        return max(self.warmup_init_lr, min(self.max_lr, self.decay_factor * (num_updates ** -0.5)))
+
+    def reset(self):
+        for param_group in self.param_groups:
+            param_group['num_updates'] = 0
+
+    def _store(self):
+        st = None
+        n = 0
+        for g in self.param_groups:
+            for p in g['params']:
+                ref = getattr(p, "_imt_store", None)
+                s = ref() if ref is not None else None
+                if s is None or (st is not None and s is not st):
+                    return None
+                st = s
+                n += 1
+        if st is None or n != len(st.entries):
+            return None
+        return st
+
+    def zero_grad(self, set_to_none: bool = False):
+        st = self._store()
+        if st is not None and st.valid():
+            st.zero_grad()
+            st.attach_grad_views()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm: float = 0.0, grad_scale: float = 1.0, zero_grad: bool = False):
+        if closure is not None:
+            raise ValueError("closures are not supported")
+        st = self._store()
+        if st is None:
+            # parameters that do not (all) live in one flat store: generic per-tensor path on the GPU
+            self._generic_step(max_grad_norm, grad_scale)
+        else:
+            st.ensure()
+            g = self.param_groups[0]
+            step = g['num_updates'] + 1
+            m, v = st.moments()
+            sumsq = None
+            if max_grad_norm and max_grad_norm > 0:
+                if self._sumsq is None or self._sumsq.device != st.flat.device:
+                    self._sumsq = torch.zeros(1, device=st.flat.device)
+                self._sumsq.zero_()
+                O.sumsq(st.grad, self._sumsq)
+                sumsq = self._sumsq
+                self.last_grad_norm_sq = sumsq
+            O.clip_adam(st.flat, st.grad, m, v, st.shadow_buffer_for_optimizer(), sumsq, float(max_grad_norm or 0.0),
+                        float(grad_scale), float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], step,
+                        zero_grad=zero_grad)
+            if st.shadow_buffer_for_optimizer() is not None:
+                st.note_shadow_written_by_optimizer()
+            else:
+                st.mark_master_changed()
+        for param_group in self.param_groups:
+            param_group['num_updates'] += 1
+            param_group['lr'] = self.get_lr_for_step(param_group['num_updates'])
+
+    def _generic_step(self, max_grad_norm, grad_scale):
+        params = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
+        if grad_scale != 1.0:
+            for p in params:
+                p.grad.mul_(grad_scale)
+        if max_grad_norm and max_grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+        for g in self.param_groups:
+            b1, b2 = g['betas']
+            t = g['num_updates'] + 1
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if not state:
+                    state['exp_avg'] = torch.zeros_like(p)
+                    state['exp_avg_sq'] = torch.zeros_like(p)
+                m, v = state['exp_avg'], state['exp_avg_sq']
+                m.mul_(b1).add_(p.grad, alpha=1 - b1)
+                v.mul_(b2).addcmul_(p.grad, p.grad, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(g['eps'])
+                p.addcdiv_(m, denom, value=-g['lr'] / (1 - b1 ** t))
+
+
+# ----------------------------------------------------------------------------------------- host batch construction
+def _mass_span_start(length_hint: int) -> int:
+    """Start of the masked span: 20% from position 1, 20% from the middle bound, 60% uniformly in [2, bound]
+    (same draw order as the reference, src/utils.py:52-60, so seeded runs produce the same batches)."""
+    draw = random.random()
+    if draw > 0.8:
+        return 1
+    if draw > 0.6:
+        return length_hint
+    return random.randint(2, length_hint) if length_hint >= 2 else 2
+
+
+def mass_mask(mask_prob, pad_indices, src_text, text_processor) -> Dict:
+    """MASS batch construction on the host (semantics of src/utils.py:41-78): per row a contiguous span of
+    int(len/2) tokens is hidden from the encoder; the decoder is fed the span shifted right (``to_recover``) with
+    its ORIGINAL positions (``positions``); hidden tokens are replaced 80/10/10 by <mask>/random/unchanged."""
+    assert 0 < mask_prob < 1
+    n_rows, width = src_text.size()
+    pad_id = text_processor.pad_token_id()
+    span_mask = torch.zeros((n_rows, width), dtype=torch.bool)
+    spans, span_pos = [], []
+    bounds = pad_indices - (1 - mask_prob) * pad_indices
+    for row in range(n_rows):
+        span_len = int(pad_indices[row] / 2)
+        first = _mass_span_start(int(math.ceil(bounds[row])))
+        last = first + span_len
+        span_mask[row, first:last] = True
+        spans.append(src_text[row, first - 1:last])
+        span_pos.append(torch.arange(first - 1, last))
+    to_recover = pad_sequence(spans, batch_first=True, padding_value=pad_id)
+    positions = pad_sequence(span_pos, batch_first=True, padding_value=int(width) - 1)
+
+    targets = src_text[:, 1:][span_mask[:, 1:]]
+    originals = src_text[span_mask]
+    n_special = len(text_processor.special_tokens)
+    vocab = text_processor.vocab_size()
+    mask_id = text_processor.mask_token_id()
+    replaced = []
+    for k in range(originals.size(0)):
+        draw = random.random()
+        if draw < 0.8:
+            replaced.append(mask_id)
+        elif draw < 0.9:
+            replaced.append(random.randint(n_special, vocab - 1))
+        else:
+            replaced.append(int(originals[k]))
+    src_text[span_mask] = torch.tensor(replaced, dtype=torch.long)
+    return {"src_mask": span_mask, "targets": targets, "src_text": src_text, "to_recover": to_recover,
+            "positions": positions, "mask_idx": originals}
+
+
+def mass_unmask(src_text, src_mask, masked_ids):
+    """Undo mass_mask in place after the step (src/utils.py:81-82)."""
+    src_text[src_mask] = masked_ids

@@ -35,6 +35,20 @@ extern "C" {
 int imt_version(void);
 const char* imt_last_error(void);
 
+/* Optional per-launch profiler used by bench.py for the roofline object: when enabled, every kernel launch is
+ * bracketed by two hipEvents recorded on the launch stream.  imt_prof_report waits for the recorded events
+ * (host-side), aggregates per kernel kind and clears the log.  flops/bytes are the ALGORITHMIC figures of the
+ * launches (2*M*N*K per GEMM; minimal operand traffic for the HBM-bound kernels).  Off by default. */
+typedef struct imt_prof_row {
+  char kind[48];
+  int64_t launches;
+  double total_ms;
+  double flops;
+  double bytes;
+} imt_prof_row;
+int imt_prof_enable(int on);
+int imt_prof_report(imt_prof_row* rows, int max_kinds);
+
 /* ------------------------------------------------------------------ GEMM (all nn.Linear fwd/bwd on the path)
  * layout IMT_NT: C[M,N] = A[M,K] * B[N,K]^T   (y = x W^T : BertSelfAttention.query/key/value, *.dense,
  *                                              BertOutputLayer.layer -- src/bert_seq2seq.py:6-12)
@@ -73,11 +87,12 @@ typedef struct imt_gemm_args {
   float alpha;
   float dropout_p;
   uint64_t dropout_seed;
+  const float* alpha_dev; /* nullable device scalar multiplied into alpha (upstream loss gradient, no host sync) */
 } imt_gemm_args;
 int imt_gemm(const imt_gemm_args* a, void* stream);
 
-/* column sums: out[n] (+)= sum_m X[m,n]  -> bias gradients (fp32, accumulated). */
-int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, void* stream);
+/* column sums: out[n] += scale * sum_m X[m,n]  -> bias gradients (fp32, accumulated); scale_dev nullable. */
+int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, const float* scale_dev, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm (torch.nn.LayerNorm, eps 1e-12)
  * fwd: y = (x - mean) * rstd * gamma + beta ; saves mean/rstd (fp32, [rows]) for backward.
@@ -183,6 +198,73 @@ int imt_clip_adam(float* p, float* g, float* m, float* v, void* p_bf16, int64_t 
 int imt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int imt_gated_mix(int dtype, const void* a, const void* b, const void* gate, void* out, int64_t rows, int d,
                   void* stream);
+
+
+/* ------------------------------------------------------------------ whole encoder / decoder stacks
+ * The host-side runtime that chains the kernels above for BertEncoderModel.forward (src/bert_seq2seq.py:103-144)
+ * and BertDecoderModel.forward (src/bert_seq2seq.py:40-91) and their backward passes.  All tensors live in
+ * caller-owned memory: `params` is the FLAT parameter buffer in the compute dtype (fp32 master, or its bf16
+ * shadow), `grads` the FLAT fp32 gradient buffer with the same element offsets; `ws` is a caller-allocated
+ * workspace of imt_stack_workspace_bytes() bytes that carries the saved activations from forward to backward.
+ * Offsets are in ELEMENTS; -1 = absent.  q|k|v weights (and biases) of one attention block are contiguous
+ * ([3d,d]) so the three projections run as one GEMM.
+ */
+typedef struct imt_attn_block {
+  int64_t qkv_w, qkv_b; /* self.query|key|value .weight [3d,d], .bias [3d] */
+  int64_t o_w, o_b;     /* output.dense */
+  int64_t ln_g, ln_b;   /* output.LayerNorm */
+} imt_attn_block;
+
+typedef struct imt_layer_desc {
+  imt_attn_block self_attn;
+  imt_attn_block cross_attn; /* qkv_w == -1 when the layer has no crossattention */
+  int64_t ff1_w, ff1_b;      /* intermediate.dense [ff,d] */
+  int64_t ff2_w, ff2_b;      /* output.dense [d,ff] */
+  int64_t ln2_g, ln2_b;      /* output.LayerNorm */
+} imt_layer_desc;
+
+typedef struct imt_stack_desc {
+  int32_t dtype;
+  int32_t d, heads, ff, vocab, max_pos, n_types, n_layers;
+  int32_t is_decoder;
+  int32_t reserved;
+  int64_t pad_id;
+  float ln_eps, hidden_dropout, attn_dropout;
+  float reserved_f;
+  int64_t emb_word, emb_pos, emb_type, emb_ln_g, emb_ln_b;
+  const imt_layer_desc* layers; /* HOST pointer, n_layers entries */
+  const void* params;           /* device, compute dtype */
+  float* grads;                 /* device, fp32 (may be NULL for inference) */
+} imt_stack_desc;
+
+typedef struct imt_stack_io {
+  int32_t B, T;              /* batch, sequence length of this stack's own tokens */
+  int32_t Tk;                /* decoder: encoder sequence length */
+  int32_t training;          /* 1: apply dropout (seeded) */
+  const int64_t* ids;        /* [B,T] */
+  const int64_t* type_ids;   /* [B,T] or NULL (zeros) */
+  const int64_t* pos_ids;    /* [B,T] or NULL (arange) */
+  const uint8_t* key_mask;   /* self-attention key mask [B,T]: encoder attention_mask / decoder 2-D tgt mask, or NULL */
+  const uint8_t* query_mask; /* decoder: tgt_mask factor of future_mask [B,T] or NULL */
+  const uint8_t* mask3d;     /* decoder: arbitrary [B,T,T] tgt_attention_mask or NULL */
+  int32_t causal;            /* decoder self-attention causal flag */
+  int32_t reserved;
+  const void* enc_states;    /* decoder: [B,Tk,d] (compute dtype) */
+  const uint8_t* enc_mask;   /* decoder: encoder_attention_mask [B,Tk] or NULL (ones) */
+  void* out;                 /* [B,T,d] final hidden states (compute dtype) */
+  uint64_t dropout_seed;
+  /* backward only */
+  const void* d_out;         /* [B,T,d] gradient of `out` */
+  void* d_enc_states;        /* decoder: [B,Tk,d] gradient w.r.t. enc_states, OVERWRITTEN */
+} imt_stack_io;
+
+int64_t imt_stack_workspace_bytes(const imt_stack_desc* m, int B, int T, int Tk);
+int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, void* stream);
+/* backward over layers [layer_lo, layer_hi) in reverse order (layer_hi == n_layers first); the embedding
+ * backward runs when layer_lo == 0.  Splitting lets the caller launch gradient all-reduce buckets between
+ * segments (RCCL on a side stream).  Parameter gradients are accumulated into m->grads. */
+int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, int layer_lo,
+                       int layer_hi, void* stream);
 
 #ifdef __cplusplus
 }
