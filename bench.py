@@ -74,12 +74,14 @@ def cpu_baseline(c, seconds_budget=25.0):
     of the same workload: the C1 model with a batch of 8 of the 64 sentences, full train step."""
     from oracle import reference_model as R
     try:
-        cores = len(os.sched_getaffinity(0))  # the cgroup/affinity share, not the host's core count
+        cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, cores))
+    # a 1-GPU box grants a 16-CPU share whatever the host's core count (256 threads thrash: 240 s/step measured)
+    cores = max(1, min(16, cores))
+    torch.set_num_threads(cores)
     print("[bench] cpu_baseline: oracle train step on %d host threads ..." % cores, file=sys.stderr, flush=True)
-    Bs = max(1, c["B"] // 8)
+    Bs = max(1, c["B"] // 16)
     tp = R.SyntheticTextProcessor(c["V"])
     torch.manual_seed(1234)
     m = R.Seq2Seq(tp, lang_dec=False, enc_layer=c["enc"], dec_layer=c["dec"], embed_dim=c["d"], intermediate_dim=c["ff"],
@@ -99,8 +101,8 @@ def cpu_baseline(c, seconds_budget=25.0):
         print("[bench] cpu_baseline: step %d done at %.1f s" % (n, time.time() - t0), file=sys.stderr, flush=True)
     dt = time.time() - t0
     return {"value": toks / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d train steps of the C1 model on %d of the 64 sentences ([%d,%d] src/tgt), fp32 torch eager, "
-                      "dropout 0.1 (oracle/reference_model.py)" % (n, Bs, Bs, c["S"])}
+            "sample": "%d full train steps (fwd+loss+bwd+clip+Adam) of the C1 model on %d of the 64 sentences "
+                      "([%d,%d] src/tgt), fp32 torch eager, dropout 0.1 (oracle/reference_model.py)" % (n, Bs, Bs, c["S"])}
 
 
 def profile_pass(step_fn, steps=2):
@@ -179,7 +181,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     rows = profile_pass(step) if rank == 0 else []
     if world > 1:
