@@ -31,6 +31,8 @@ class GemmArgs(Structure):
         ("alpha", c_float), ("dropout_p", c_float),
         ("dropout_seed", c_uint64),
         ("alpha_dev", c_void_p),
+        ("a_colsum", c_void_p),
+        ("force_general", c_int32), ("force_pipeline", c_int32),
     ]
 
 
@@ -104,10 +106,11 @@ SIGNATURES = {
     "imt_version": (c_int, []),
     "imt_last_error": (c_char_p, []),
     "imt_gemm": (c_int, [POINTER(GemmArgs), _P]),
+    "imt_gemm_grouped_tn": (c_int, [POINTER(GemmArgs), c_int, _P]),
     "imt_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "imt_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, _P]),
     "imt_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, c_float,
-                                  c_uint64, _P]),
+                                  c_uint64, _P, _P]),
     "imt_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "imt_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P]),
     "imt_attention_fwd": (c_int, [POINTER(AttnArgs), _P]),

@@ -354,9 +354,8 @@ class _LinearFn(torch.autograd.Function):
         dx = O.gemm(dy, w, O.IMT_NN) if ctx.needs_input_grad[0] else None
         gw = store.grad[ctx.wo:ctx.wo + N * K].view(N, K)
         sk = max(1, min(M // 256, 512 // max(1, ((N + 127) // 128) * ((K + 127) // 128))))
-        O.gemm(dy, x, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk)
-        if ctx.bo >= 0:
-            O.colsum(dy, store.grad[ctx.bo:ctx.bo + N])
+        O.gemm(dy, x, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk,
+               a_colsum=store.grad[ctx.bo:ctx.bo + N] if ctx.bo >= 0 else None)
         store.attach_grad_views()
         return dx, None, None, None
 

@@ -228,7 +228,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   load_row_frags<T, DH>(dof, dOb, p.lddo, q0, p.Tq);
   const bool query_ok = (p.query_mask && i < p.Tq) ? (p.query_mask[(int64_t)b * p.Tq + i] != 0) : true;
   const int64_t srow = ((int64_t)b * p.H + h) * p.Tq + (i < p.Tq ? i : 0);
-  const float lse_i = p.lse[srow], delta_i = p.delta[srow];
+  const float lse_i = p.lse[srow];
+  // delta_i = rowsum(dO * O) of this lane's query row, computed here from the row fragments (the lanes r, r+16, r+32,
+  // r+48 hold the four 16-byte chunks of each 64-byte k-step) and published for the dK/dV kernel that runs next.
+  float delta_i = 0.f;
+  {
+    const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)b * p.Tq * p.ldo + h * DH;
+    frag_t of[NS];
+    load_row_frags<T, DH>(of, Ob, p.ldo, q0, p.Tq);
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+      for (int e = 0; e < Frag<T>::EPC; ++e) delta_i += (float)dof[ks][e] * (float)of[ks][e];
+    delta_i += __shfl_xor(delta_i, 16, 64);
+    delta_i += __shfl_xor(delta_i, 32, 64);
+    if (g == 0 && i < p.Tq) p.delta[srow] = delta_i;
+  }
 
   f32x4 dq[NDT];
 #pragma unroll
@@ -417,14 +432,8 @@ template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
   return IMT_OK;
 }
 template <typename T, int DH> int bwd_launch(const AttnP& p, hipStream_t st) {
-  const int64_t total = (int64_t)p.B * p.Tq * p.H * (DH / 4);
   const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
   const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
-  {
-    ImtProfScope prof("attn_bwd_delta", 0.0, (double)p.B * p.H * p.Tq * DH * sizeof(T) * 2.0, st);
-    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3(imt_cdiv(total, 256)), dim3(256), 0, st, p);
-    IMT_CHECK_LAUNCH();
-  }
   {
     ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dq_bf16" : "attn_bwd_dq_f32", 6.0 * work, io * 1.5, st);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64), p.H, p.B), dim3(256), 0, st, p);

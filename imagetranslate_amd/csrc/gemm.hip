@@ -2,27 +2,38 @@
 //
 // Tile: 128 x 128 output per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles),
 // K advanced 128 BYTES per tile row (64 bf16 / 32 fp32) so the LDS geometry is the same for both types.
-// Operands are staged global -> registers -> LDS (16-B chunks, XOR-swizzled, double-buffered: the loads of
-// tile t+1 are issued before the MFMAs of tile t and written to the other buffer after them; one barrier
-// per K tile).  K-contiguous operands are read back with ds_read_b128; K-strided operands (the N-contiguous
-// B of NN, both operands of TN) with the gfx950 transposed LDS read ds_read_b64_tr_b16 (bf16) or scalar
-// reads (fp32) -- no operand is ever transposed through HBM.
-// The product is accumulated as C^T tiles (mfma(Bfrag, Afrag)) so each lane owns 4 consecutive n of one m:
-// bias / residual / aux accesses and the C store are 8- or 16-byte vectors.
+// K-contiguous operands are read back from XOR-swizzled LDS with ds_read_b128; K-strided operands (the
+// N-contiguous B of NN, both operands of TN) with the gfx950 transposed LDS read ds_read_b64_tr_b16 (bf16) or
+// scalar reads (fp32) -- no operand is ever transposed through HBM.  The product is accumulated as C^T tiles
+// (mfma(Bfrag, Afrag)) so each lane owns 4 consecutive n of one m: bias / residual / aux accesses and the C
+// store are 8- or 16-byte vectors.
+//
+// Two main loops share the tile compute and the epilogue:
+//   gemm_pipe_kernel : LDS-DMA (buffer_load ... lds, 16 B/lane) into a 3-stage ring; tile t+2 is in flight while
+//                      tile t is multiplied; ONE raw s_barrier per K tile and a COUNTED s_waitcnt vmcnt(8) so the
+//                      prefetch survives the barrier (cdna guide: "Pipelining across barriers").  The swizzle is
+//                      applied to the per-lane SOURCE address (the DMA destination is lane-linear).  Used whenever
+//                      the K extent of a block is a whole number of tiles.
+//   gemm_kernel      : register-staged double buffer with predicated (zero-filling) loads: ragged K / tiny K.
 #include "mma.hpp"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int TILE_BYTES = 16384;            // one operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
 
-template <typename T, bool KCONTIG> struct Stage {
-  // tile bytes = 16 KiB either way
-  static constexpr int EPC = 16 / sizeof(T);                       // elements per 16-B chunk
-  static constexpr int BK = 128 / sizeof(T);                       // K elements per tile
-  static constexpr int RB = KCONTIG ? 128 : 128 * sizeof(T);       // LDS row bytes
-  static constexpr int CPR = RB / 16;                              // chunks per row
+template <typename T, bool KCONTIG> struct TileGeom {
+  static constexpr int EPC = 16 / sizeof(T);                  // elements per 16-B chunk
+  static constexpr int BK = 128 / sizeof(T);                  // K elements per tile
+  static constexpr int RB = KCONTIG ? 128 : 128 * sizeof(T);  // LDS row bytes
+  static constexpr int CPR = RB / 16;                         // chunks per row
+};
+
+// ------------------------------------------------------------------------------------------------ register staging
+template <typename T, bool KCONTIG> struct Stage : TileGeom<T, KCONTIG> {
+  using G = TileGeom<T, KCONTIG>;
   u32x4 r[4];
-
   // KCONTIG: operand[rows = M or N][K], tile rows = 128 operand rows, row chunk c covers k0 + c*EPC
   // else   : operand[K][cols = M or N], tile rows = BK k-rows, row chunk c covers col0 + c*EPC
   IMT_DEVICE void load(const T* __restrict__ base, int64_t ld, int row0, int nrows, int k0, int K) {
@@ -30,11 +41,11 @@ template <typename T, bool KCONTIG> struct Stage {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = i * NTHREADS + tid;
-      const int tr = q / CPR, c = q % CPR;
+      const int tr = q / G::CPR, c = q % G::CPR;
       int64_t grow, gcol;
       bool ok;
-      if (KCONTIG) { grow = row0 + tr; gcol = k0 + c * EPC; ok = (grow < nrows) && (gcol < K); }
-      else         { grow = k0 + tr;   gcol = row0 + c * EPC; ok = (grow < K) && (gcol < nrows); }
+      if (KCONTIG) { grow = row0 + tr; gcol = k0 + c * G::EPC; ok = (grow < nrows) && (gcol < K); }
+      else         { grow = k0 + tr;   gcol = row0 + c * G::EPC; ok = (grow < K) && (gcol < nrows); }
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ok) v = *reinterpret_cast<const u32x4*>(base + grow * ld + gcol);
       r[i] = v;
@@ -45,8 +56,40 @@ template <typename T, bool KCONTIG> struct Stage {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = i * NTHREADS + tid;
-      const int tr = q / CPR, c = q % CPR;
-      *reinterpret_cast<u32x4*>(tile + tile_off<RB>(tr, c)) = r[i];
+      const int tr = q / G::CPR, c = q % G::CPR;
+      *reinterpret_cast<u32x4*>(tile + tile_off<G::RB>(tr, c)) = r[i];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ LDS-DMA staging
+// One wave instruction writes 64 lanes x 16 B = 1 KiB of LDS linearly ("piece"); a 16-KiB tile = 16 pieces, wave w
+// issues pieces w, w+4, w+8, w+12.  Lane l of piece p lands on physical chunk q = 64p + l = (row tr, chunk pc); it
+// must therefore FETCH logical chunk c = pc ^ swz(tr) of that row (the XOR swizzle is an involution).
+template <typename T, bool KCONTIG> struct Dma : TileGeom<T, KCONTIG> {
+  using G = TileGeom<T, KCONTIG>;
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[4];    // byte offset of this lane's chunk for k0 = 0
+  int kadv;       // byte advance per K tile
+  IMT_DEVICE void init(const T* base, int64_t ld, int64_t valid_bytes, int row0, int kbeg) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)valid_bytes, 0x00020000);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 64 * (4 * i + wave) + lane;
+      const int tr = q / G::CPR, pc = q % G::CPR;
+      const int c = pc ^ swz<G::RB>(tr);
+      if (KCONTIG) voff[i] = (int)((((int64_t)(row0 + tr)) * ld + kbeg + c * G::EPC) * (int64_t)sizeof(T));
+      else         voff[i] = (int)((((int64_t)(kbeg + tr)) * ld + row0 + c * G::EPC) * (int64_t)sizeof(T));
+    }
+    kadv = KCONTIG ? 128 : (int)(G::BK * ld * (int64_t)sizeof(T));
+  }
+  IMT_DEVICE void issue(char* tile, int t) const {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (4 * i + wave) * 1024), 16,
+                                               voff[i] + t * kadv, 0, 0, 0);
     }
   }
 };
@@ -58,88 +101,76 @@ struct EpiParams {
   int atomic;
   float alpha; const float* alpha_dev;
   float inv_keep; uint32_t drop_thresh; uint64_t seed;
+  float* a_colsum;  // TN only: a_colsum[m] += alpha * sum_k A[k][m]   (bias gradient fused into the dW GEMM)
 };
 
+// ------------------------------------------------------------------------------------------------ tile product
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-                                                        int64_t ldb, int M, int N, int K, int k_per_split,
-                                                        EpiParams ep) {
-  constexpr bool A_KC = (LAYOUT != IMT_TN);  // A is K-contiguous for NT, NN
-  constexpr bool B_KC = (LAYOUT == IMT_NT);  // B is K-contiguous for NT only
-  typedef Stage<T, A_KC> SA;
-  typedef Stage<T, B_KC> SB;
+IMT_DEVICE void compute_tile(f32x4 (&acc)[4][4], const char* ta, const char* tb, int wm, int wn) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  typedef TileGeom<T, A_KC> GA;
+  typedef TileGeom<T, B_KC> GB;
   typedef typename Frag<T>::type frag_t;
-  constexpr int BK = SA::BK;
-  constexpr int KSTEP = Frag<T>::KSTEP;  // k per fragment step (64 bytes)
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // buffer b: A tile at smem + b*32768, B tile 16 KiB after it
-
-  // XCD-aware block order (T1): consecutive ids on one XCD walk neighbouring tiles.
-  const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
-  const int nwg = nbx * nby;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  constexpr int KSTEP = Frag<T>::KSTEP;
+#pragma unroll
+  for (int s = 0; s < GA::BK / KSTEP; ++s) {
+    frag_t fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (A_KC) fa[i] = lds_frag_kcontig<T, GA::RB>(ta, wm + 16 * i, 4 * s);
+      else      fa[i] = KStrided<T, GA::RB>::load(ta, s * KSTEP, wm + 16 * i);
+      if (B_KC) fb[i] = lds_frag_kcontig<T, GB::RB>(tb, wn + 16 * i, 4 * s);
+      else      fb[i] = KStrided<T, GB::RB>::load(tb, s * KSTEP, wn + 16 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma16(acc[i][j], fb[j], fa[i]);  // C^T tile: rows <- n, cols <- m
   }
-  const int m0 = (bid / nbx) * BM, n0 = (bid % nbx) * BN;
-  const int kbeg = blockIdx.y * k_per_split;
-  const int kend = min(K, kbeg + k_per_split);
+}
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int lr = lane & 15, lg = lane >> 4;
-
-  f32x4 acc[4][4];
+// column sums of the K-strided A tile [BK][128] sitting in LDS (TN): thread t owns chunk t % CPR of rows t/CPR + ...
+template <typename T> struct ColSum {
+  typedef TileGeom<T, false> G;
+  static constexpr int EPC = G::EPC;
+  float s[EPC];
+  IMT_DEVICE void clear() {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  SA sa; SB sb;
-  const int nt = (kend - kbeg + BK - 1) / BK;
-  if (nt > 0) {
-    sa.load(A, lda, m0, M, kbeg, kend);
-    sb.load(B, ldb, n0, N, kbeg, kend);
-    sa.store(smem);
-    sb.store(smem + 16384);
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
   }
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) {
-      sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend);
-      sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend);
+  IMT_DEVICE void add_tile(const char* ta) {
+    constexpr int RSTEP = NTHREADS / G::CPR;  // rows covered per pass
+    const int c = threadIdx.x % G::CPR, r0 = threadIdx.x / G::CPR;
+#pragma unroll
+    for (int i = 0; i < G::BK / RSTEP; ++i) {
+      const int row = r0 + i * RSTEP;
+      const typename Frag<T>::type v = *reinterpret_cast<const typename Frag<T>::type*>(ta + tile_off<G::RB>(row, c));
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s[e] += (float)v[e];
     }
-    const char* ta = smem + cur * 32768;
-    const char* tb = ta + 16384;
-#pragma unroll
-    for (int s = 0; s < BK / KSTEP; ++s) {
-      frag_t fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (A_KC) fa[i] = lds_frag_kcontig<T, SA::RB>(ta, wm + 16 * i, 4 * s);
-        else      fa[i] = KStrided<T, SA::RB>::load(ta, s * KSTEP, wm + 16 * i);
-        if (B_KC) fb[i] = lds_frag_kcontig<T, SB::RB>(tb, wn + 16 * i, 4 * s);
-        else      fb[i] = KStrided<T, SB::RB>::load(tb, s * KSTEP, wn + 16 * i);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mma16(acc[i][j], fb[j], fa[i]);  // C^T tile: rows <- n, cols <- m
-    }
-    if (t + 1 < nt) {
-      sa.store(smem + (cur ^ 1) * 32768);
-      sb.store(smem + (cur ^ 1) * 32768 + 16384);
-    }
+  }
+  // reduce over the threads that share a chunk column, then one atomic per column
+  IMT_DEVICE void flush(char* smem, float* out, int m0, int M, float alpha) {
+    constexpr int RSTEP = NTHREADS / G::CPR;
+    float* red = reinterpret_cast<float*>(smem);  // [RSTEP][128]
+    const int c = threadIdx.x % G::CPR, r0 = threadIdx.x / G::CPR;
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[r0 * 128 + c * EPC + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float t = 0.f;
+      for (int j = 0; j < RSTEP; ++j) t += red[j * 128 + threadIdx.x];
+      if (m0 + (int)threadIdx.x < M) atomicAdd(out + m0 + threadIdx.x, t * alpha);
+    }
   }
+};
 
-  // ---------------------------------------------------------------- epilogue
-  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
-  // lane owns C[m = m0+wm+16i+lr][n = n0+wn+16j+4lg .. +3]
+// ------------------------------------------------------------------------------------------------ epilogue
+// lane owns C[m = m0+wm+16i+lr][n = n0+wn+16j+4lg .. +3]
+template <typename T>
+IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep, float alpha) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* resid = reinterpret_cast<const T*>(ep.resid);
   T* aux = reinterpret_cast<T*>(ep.aux);
@@ -216,31 +247,296 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const T* __restrict__ A,
   }
 }
 
+// XCD-aware block order (T1): consecutive ids on one XCD walk neighbouring tiles (bijective for any grid size).
+IMT_DEVICE void tile_origin(int M, int N, int& m0, int& n0) {
+  const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+  const int nwg = nbx * nby;
+  int bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  m0 = (bid / nbx) * BM;
+  n0 = (bid % nbx) * BN;
+}
+
+// ------------------------------------------------------------------------------------------------ general kernel
 template <typename T, int LAYOUT>
-int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_split, hipStream_t st) {
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                        int64_t ldb, int M, int N, int K, int k_per_split, EpiParams ep) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  typedef Stage<T, A_KC> SA;
+  typedef Stage<T, B_KC> SB;
+  constexpr int BK = SA::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // buffer b: A tile at b*32 KiB, B tile 16 KiB later
+
+  int m0, n0;
+  tile_origin(M, N, m0, n0);
+  const int kbeg = blockIdx.y * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ColSum<T> cs;
+  cs.clear();
+  const bool do_colsum = (LAYOUT == IMT_TN) && ep.a_colsum && n0 == 0;
+
+  SA sa; SB sb;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  if (nt > 0) {
+    sa.load(A, lda, m0, M, kbeg, kend);
+    sb.load(B, ldb, n0, N, kbeg, kend);
+    sa.store(smem);
+    sb.store(smem + TILE_BYTES);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend);
+      sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend);
+    }
+    const char* ta = smem + cur * STAGE_BYTES;
+    compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
+    if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
+    if (t + 1 < nt) {
+      sa.store(smem + (cur ^ 1) * STAGE_BYTES);
+      sb.store(smem + (cur ^ 1) * STAGE_BYTES + TILE_BYTES);
+    }
+    __syncthreads();
+  }
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, alpha);
+  if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem, ep.a_colsum, m0, M, alpha);
+}
+
+// ------------------------------------------------------------------------------------------------ high-occupancy kernel
+// Single 32-KiB LDS buffer + register prefetch: two barriers per K tile, but three workgroups (12 waves) per CU,
+// i.e. three tiles of loads in flight per CU and other blocks' MFMAs to fill every barrier / latency bubble.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_sb_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                              int64_t ldb, int M, int N, int K, int k_per_split, EpiParams ep) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  typedef Stage<T, A_KC> SA;
+  typedef Stage<T, B_KC> SB;
+  constexpr int BK = SA::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int m0, n0;
+  tile_origin(M, N, m0, n0);
+  const int kbeg = blockIdx.y * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ColSum<T> cs;
+  cs.clear();
+  const bool do_colsum = (LAYOUT == IMT_TN) && ep.a_colsum && n0 == 0;
+  SA sa; SB sb;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  if (nt > 0) {
+    sa.load(A, lda, m0, M, kbeg, kend);
+    sb.load(B, ldb, n0, N, kbeg, kend);
+  }
+  for (int t = 0; t < nt; ++t) {
+    sa.store(smem);
+    sb.store(smem + TILE_BYTES);
+    __syncthreads();
+    if (t + 1 < nt) {
+      sa.load(A, lda, m0, M, kbeg + (t + 1) * BK, kend);
+      sb.load(B, ldb, n0, N, kbeg + (t + 1) * BK, kend);
+    }
+    compute_tile<T, LAYOUT>(acc, smem, smem + TILE_BYTES, wm, wn);
+    if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(smem);
+    __syncthreads();
+  }
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, alpha);
+  if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem, ep.a_colsum, m0, M, alpha);
+}
+
+// ------------------------------------------------------------------------------------------------ pipelined kernel
+constexpr int NST = 3;  // LDS ring depth (96 KiB): tile t+2 in flight while tile t is multiplied
+
+template <typename T, int LAYOUT, int NSTG>
+__global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict__ A, int64_t lda, int64_t a_bytes,
+                                                             const T* __restrict__ B, int64_t ldb, int64_t b_bytes, int M, int N,
+                                                             int K, int k_per_split, EpiParams ep) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  constexpr int BK = TileGeom<T, A_KC>::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS in this one array (second-object trap)
+
+  int m0, n0;
+  tile_origin(M, N, m0, n0);
+  const int kbeg = blockIdx.y * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  const int nt = (kend - kbeg) / BK;  // host guarantees (kend - kbeg) % BK == 0
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  Dma<T, A_KC> da; Dma<T, B_KC> db;
+  da.init(A, lda, a_bytes, m0, kbeg);
+  db.init(B, ldb, b_bytes, n0, kbeg);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ColSum<T> cs;
+  cs.clear();
+  const bool do_colsum = (LAYOUT == IMT_TN) && ep.a_colsum && n0 == 0;
+
+  // K-order rotation: workgroups that run at the same time start at different K offsets, so they do not all hit the
+  // same L2 / memory channels in lock-step (row strides are powers of two).  Summation order differs per block only.
+  const int phase = nt > 0 ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nt) : 0;
+  auto ktile = [&](int t) { const int k = t + phase; return k >= nt ? k - nt : k; };
+  // prologue: tiles 0 .. NSTG-2 in flight (8 DMA instructions per wave per tile: 4 for A, 4 for B)
+#pragma unroll
+  for (int s0 = 0; s0 < NSTG - 1; ++s0)
+    if (s0 < nt) { da.issue(smem + s0 * STAGE_BYTES, ktile(s0)); db.issue(smem + s0 * STAGE_BYTES + TILE_BYTES, ktile(s0)); }
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    // tile t has landed once all but the (NSTG-2) newest tiles' DMAs are done; the barrier then (a) publishes every
+    // wave's pieces of tile t and (b) proves every wave finished reading the buffer the next DMA overwrites.
+    const int newer = min(NSTG - 2, nt - 1 - t);
+    if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (t + NSTG - 1 < nt) {
+      const int nxt = (cur == 0) ? NSTG - 1 : cur - 1;  // (cur + NSTG - 1) % NSTG
+      da.issue(smem + nxt * STAGE_BYTES, ktile(t + NSTG - 1));
+      db.issue(smem + nxt * STAGE_BYTES + TILE_BYTES, ktile(t + NSTG - 1));
+    }
+    const char* ta = smem + cur * STAGE_BYTES;
+    compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
+    if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
+    cur = (cur + 1 == NSTG) ? 0 : cur + 1;
+  }
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, alpha);
+  if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem, ep.a_colsum, m0, M, alpha);
+}
+
+
+// ------------------------------------------------------------------------------------------------ grouped weight gradients
+// All weight-gradient GEMMs of one transformer layer (dW = dy^T x, K = tokens) in ONE launch: each has only 16-64
+// output tiles, so separately they either idle most CUs or need split-K atomics; together they are ~one tile per
+// CU with the full K per block (long steady-state LDS-DMA pipeline, direct fp32 accumulate, no atomics).
+constexpr int MAX_GROUP = 8;
+struct GroupProblem {
+  const void* A; const void* B; float* C; float* a_colsum;
+  int64_t lda, ldb, ldc, a_bytes, b_bytes;
+  int M, N, K, tile_start;
+};
+struct GroupArgs { int count; int total_tiles; float alpha; int pad; GroupProblem p[MAX_GROUP]; };
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_grouped_tn_kernel(GroupArgs g) {
+  constexpr int BK = TileGeom<T, false>::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_GROUP; ++i)
+    if (i < g.count && (int)blockIdx.x >= g.p[i].tile_start) pi = i;
+  const GroupProblem& P = g.p[pi];
+  const int M = P.M, N = P.N, K = P.K;
+  const int nbx = (N + BN - 1) / BN;
+  const int local = blockIdx.x - P.tile_start;
+  const int m0 = (local / nbx) * BM, n0 = (local % nbx) * BN;
+  const int nt = K / BK;
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  Dma<T, false> da; Dma<T, false> db;
+  da.init(reinterpret_cast<const T*>(P.A), P.lda, P.a_bytes, m0, 0);
+  db.init(reinterpret_cast<const T*>(P.B), P.ldb, P.b_bytes, n0, 0);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ColSum<T> cs;
+  cs.clear();
+  const bool do_colsum = P.a_colsum && n0 == 0;
+
+  if (nt > 0) { da.issue(smem, 0); db.issue(smem + TILE_BYTES, 0); }
+  if (nt > 1) { da.issue(smem + STAGE_BYTES, 1); db.issue(smem + STAGE_BYTES + TILE_BYTES, 1); }
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (t + 2 < nt) {
+      const int nxt = (cur + 2 >= NST) ? cur + 2 - NST : cur + 2;
+      da.issue(smem + nxt * STAGE_BYTES, t + 2);
+      db.issue(smem + nxt * STAGE_BYTES + TILE_BYTES, t + 2);
+    }
+    const char* ta = smem + cur * STAGE_BYTES;
+    compute_tile<T, IMT_TN>(acc, ta, ta + TILE_BYTES, wm, wn);
+    if (do_colsum) cs.add_tile(ta);
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
+  }
+  EpiParams ep;
+  ep.C = P.C; ep.ldc = P.ldc; ep.c_f32 = 1; ep.accumulate = 1;
+  ep.bias = nullptr; ep.resid = nullptr; ep.ldr = 0; ep.aux = nullptr; ep.ldaux = 0; ep.aux_mode = IMT_AUX_NONE;
+  ep.atomic = 0; ep.alpha = g.alpha; ep.alpha_dev = nullptr; ep.inv_keep = 1.f; ep.drop_thresh = 0; ep.seed = 0;
+  ep.a_colsum = P.a_colsum;
+  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, g.alpha);
+  if (do_colsum) cs.flush(smem, P.a_colsum, m0, M, g.alpha);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int64_t view_bytes(int rows, int64_t ld, int inner, int es) { return rows > 0 ? ((int64_t)(rows - 1) * ld + inner) * es : 0; }
+
+template <typename T, int LAYOUT>
+int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_split, int variant, hipStream_t st) {
   const int nbx = imt_cdiv(a->N, BN), nby = imt_cdiv(a->M, BM);
   dim3 grid(nbx * nby, splits);
   static bool attr_set = false;
   auto kern = gemm_kernel<T, LAYOUT>;
+  auto kpipe = gemm_pipe_kernel<T, LAYOUT, 3>;
+  auto kpipe4 = gemm_pipe_kernel<T, LAYOUT, 4>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpipe), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpipe4), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
     attr_set = true;
   }
   static const char* const kinds[2][3] = {{"gemm_f32_nt", "gemm_f32_nn", "gemm_f32_tn"}, {"gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn"}};
   const double es = sizeof(T), esc = ep.c_f32 ? 4.0 : es;
   ImtProfScope prof(kinds[sizeof(T) == 2][LAYOUT], 2.0 * a->M * a->N * a->K,
                     ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * esc, st);
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), 65536, st, reinterpret_cast<const T*>(a->A), a->lda,
-                     reinterpret_cast<const T*>(a->B), a->ldb, a->M, a->N, a->K, k_per_split, ep);
+  const T* A = reinterpret_cast<const T*>(a->A);
+  const T* B = reinterpret_cast<const T*>(a->B);
+  if (variant == 3) {
+    hipLaunchKernelGGL((gemm_sb_kernel<T, LAYOUT>), grid, dim3(NTHREADS), STAGE_BYTES, st, A, a->lda, B, a->ldb, a->M, a->N, a->K, k_per_split, ep);
+  } else if (variant == 2 || variant == 4) {
+    const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
+    const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
+    if (variant == 4)
+      hipLaunchKernelGGL(kpipe4, grid, dim3(NTHREADS), 4 * STAGE_BYTES, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, k_per_split, ep);
+    else
+      hipLaunchKernelGGL(kpipe, grid, dim3(NTHREADS), 3 * STAGE_BYTES, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, k_per_split, ep);
+  } else {
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), 2 * STAGE_BYTES, st, A, a->lda, B, a->ldb, a->M, a->N, a->K, k_per_split, ep);
+  }
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
 
-template <typename T> int dispatch(const imt_gemm_args* a, const EpiParams& ep, int splits, int kps, hipStream_t st) {
+template <typename T> int dispatch(const imt_gemm_args* a, const EpiParams& ep, int splits, int kps, int variant, hipStream_t st) {
   switch (a->layout) {
-    case IMT_NT: return launch<T, IMT_NT>(a, ep, splits, kps, st);
-    case IMT_NN: return launch<T, IMT_NN>(a, ep, splits, kps, st);
-    case IMT_TN: return launch<T, IMT_TN>(a, ep, splits, kps, st);
+    case IMT_NT: return launch<T, IMT_NT>(a, ep, splits, kps, variant, st);
+    case IMT_NN: return launch<T, IMT_NN>(a, ep, splits, kps, variant, st);
+    case IMT_TN: return launch<T, IMT_TN>(a, ep, splits, kps, variant, st);
   }
   imt_set_error("imt_gemm: bad layout %d", a->layout);
   return IMT_ERR_BAD_ARG;
@@ -255,6 +551,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   if (a->M == 0 || a->N == 0) return IMT_OK;
   IMT_CHECK_ARG(a->A && a->B && a->C, "imt_gemm: null operand");
   const int al = (a->dtype == IMT_BF16) ? 8 : 4;
+  const int es = (a->dtype == IMT_BF16) ? 2 : 4;
   IMT_CHECK_ARG(a->lda % al == 0 && a->ldb % al == 0, "imt_gemm: lda/ldb must be multiples of %d (16-B rows)", al);
   IMT_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "imt_gemm: A/B must be 16-B aligned");
   // contiguous extents of the vector loads must be chunk multiples
@@ -265,6 +562,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   IMT_CHECK_ARG(a->ldc % 4 == 0, "imt_gemm: ldc must be a multiple of 4");
   const int c_f32 = (a->c_dtype == IMT_F32);
   IMT_CHECK_ARG(c_f32 || a->c_dtype == a->dtype, "imt_gemm: c_dtype must be f32 or dtype");
+  IMT_CHECK_ARG(!a->a_colsum || a->layout == IMT_TN, "imt_gemm: a_colsum is a TN (weight-gradient) option");
   int splits = a->split_k > 1 ? a->split_k : 1;
   const int bk = (a->dtype == IMT_BF16) ? 64 : 32;
   int kps = a->K;
@@ -275,6 +573,18 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     splits = imt_cdiv(a->K, kps);
   }
   if (a->aux_mode != IMT_AUX_NONE) IMT_CHECK_ARG(a->aux != nullptr, "imt_gemm: aux_mode needs aux");
+  // LDS-DMA pipeline: whole K tiles only (no zero-fill needed anywhere), 32-bit buffer offsets
+  const int64_t a_rows = (a->layout == IMT_TN) ? a->K : a->M, b_rows = (a->layout == IMT_NT) ? a->N : a->K;
+  const bool pipe_ok = (a->K % bk == 0) && (a->K / bk >= 2) && (a_rows * a->lda * es < (1ll << 31)) &&
+                       (b_rows * a->ldb * es < (1ll << 31));
+  const int64_t nblocks = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN) * splits;
+  // kernel variant: 1 = register-staged double buffer (2 blocks/CU), 2 = LDS-DMA 3-stage ring (1 block/CU),
+  // 3 = single buffer + register prefetch (4 blocks/CU).  a->force_general carries a variant code for tests/tuning.
+  int variant = a->force_general;
+  // measured on MI355X (profiles/r01_v3_gemm_shapes.txt): about one wave of blocks -> the LDS-DMA ring (its long
+  // steady state wins when K >= 1024, a tie otherwise); larger grids -> three single-buffer blocks per CU.
+  if (variant == 0) variant = (pipe_ok && nblocks <= 320) ? 2 : (a->layout == IMT_TN ? 1 : 3);
+  if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;
   EpiParams ep;
   ep.C = a->C; ep.ldc = a->ldc; ep.c_f32 = c_f32; ep.accumulate = a->accumulate;
   ep.bias = a->bias; ep.resid = a->resid; ep.ldr = a->ldr;
@@ -284,7 +594,65 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   ep.drop_thresh = dropout_thresh(a->dropout_p);
   ep.inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
   ep.seed = a->dropout_seed;
+  ep.a_colsum = a->a_colsum;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == IMT_F32) return dispatch<float>(a, ep, splits, kps, st);
-  return dispatch<bf16_t>(a, ep, splits, kps, st);
+  if (a->dtype == IMT_F32) return dispatch<float>(a, ep, splits, kps, variant, st);
+  return dispatch<bf16_t>(a, ep, splits, kps, variant, st);
+}
+
+extern "C" int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* stream) {
+  IMT_CHECK_ARG(list && count >= 0, "imt_gemm_grouped_tn: bad args");
+  if (count == 0) return IMT_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  bool ok = count <= MAX_GROUP;
+  const int dtype = list[0].dtype;
+  const int bk = (dtype == IMT_BF16) ? 64 : 32, es = (dtype == IMT_BF16) ? 2 : 4, al = (dtype == IMT_BF16) ? 8 : 4;
+  int tiles = 0;
+  for (int i = 0; i < count && ok; ++i) {
+    const imt_gemm_args& a = list[i];
+    ok = a.dtype == dtype && a.layout == IMT_TN && a.c_dtype == IMT_F32 && !a.bias && !a.resid && a.aux_mode == IMT_AUX_NONE &&
+         a.dropout_p == 0.f && !a.alpha_dev && a.alpha == list[0].alpha && a.A && a.B && a.C && a.M > 0 && a.N > 0 &&
+         a.K % bk == 0 && a.K / bk >= 2 && a.lda % al == 0 && a.ldb % al == 0 && a.M % al == 0 && a.N % al == 0 && a.ldc % 4 == 0 &&
+         (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 && (int64_t)a.K * a.lda * es < (1ll << 31) &&
+         (int64_t)a.K * a.ldb * es < (1ll << 31);
+    tiles += imt_cdiv(a.M, BM) * imt_cdiv(a.N, BN);
+  }
+  if (!ok || tiles > 640) {
+    // not groupable (ragged K, too many problems, ...): individual launches with their own split-K choice
+    for (int i = 0; i < count; ++i) {
+      int rc = imt_gemm(&list[i], stream);
+      if (rc != IMT_OK) return rc;
+    }
+    return IMT_OK;
+  }
+  GroupArgs g;
+  memset(&g, 0, sizeof(g));
+  g.count = count; g.alpha = list[0].alpha;
+  int start = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < count; ++i) {
+    const imt_gemm_args& a = list[i];
+    GroupProblem& P = g.p[i];
+    P.A = a.A; P.B = a.B; P.C = reinterpret_cast<float*>(a.C); P.a_colsum = a.a_colsum;
+    P.lda = a.lda; P.ldb = a.ldb; P.ldc = a.ldc;
+    P.a_bytes = view_bytes(a.K, a.lda, a.M, es); P.b_bytes = view_bytes(a.K, a.ldb, a.N, es);
+    P.M = a.M; P.N = a.N; P.K = a.K; P.tile_start = start;
+    start += imt_cdiv(a.M, BM) * imt_cdiv(a.N, BN);
+    flops += 2.0 * a.M * a.N * a.K;
+    bytes += ((double)a.M + a.N) * a.K * es + 4.0 * a.M * a.N;
+  }
+  g.total_tiles = start;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+    attr_set = true;
+  }
+  ImtProfScope prof(dtype == IMT_BF16 ? "gemm_bf16_tn_grouped" : "gemm_f32_tn_grouped", flops, bytes, st);
+  if (dtype == IMT_F32)
+    hipLaunchKernelGGL(gemm_grouped_tn_kernel<float>, dim3(start), dim3(NTHREADS), NST * STAGE_BYTES, st, g);
+  else
+    hipLaunchKernelGGL(gemm_grouped_tn_kernel<bf16_t>, dim3(start), dim3(NTHREADS), NST * STAGE_BYTES, st, g);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
 }

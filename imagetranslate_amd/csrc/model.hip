@@ -36,12 +36,17 @@ struct LayerWs {
 struct StackWs {
   void* emb_sum; float* emb_mean; float* emb_rstd; void* x0;
   LayerWs* layers;  // host array (carved on the stack of the caller)
-  // backward scratch
-  void* d_a; void* d_b; void* d_c;  // [N,d] each
+  // backward scratch.  Every dy operand of a weight-gradient GEMM keeps its own buffer until the end of the layer,
+  // because all dW GEMMs of a layer are deferred into ONE grouped launch (imt_gemm_grouped_tn).
+  void* d_run;                       // [N,d]  running gradient w.r.t. the current block output
+  void* dpre[3]; void* ddrop[3];     // [N,d]  LN-backward outputs of the FFN / cross / self blocks (residual / dense path)
+  void* d_ctx;                       // [N,d]
   void* d_ff;                        // [N,ff]
   void* d_qkv;                       // [N,3d]
+  void* d_q;                         // [N,d]   cross-attention query gradient
   void* d_kv;                        // [Nk,2d]
   float* delta;                      // [B,H,T]
+  float* ln_partial;                 // IMT_LN_BWD_WS_FLOATS(d)
   int64_t bytes;
 };
 
@@ -74,11 +79,15 @@ void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, 
     L.pre_ln2 = c.take(N * d * es); L.mean2 = (float*)c.take(N * 4); L.rstd2 = (float*)c.take(N * 4);
     L.out = c.take(N * d * es);
   }
-  w.d_a = c.take(N * d * es); w.d_b = c.take(N * d * es); w.d_c = c.take(N * d * es);
+  w.d_run = c.take(N * d * es);
+  for (int i = 0; i < 3; ++i) { w.dpre[i] = c.take(N * d * es); w.ddrop[i] = c.take(N * d * es); }
+  w.d_ctx = c.take(N * d * es);
   w.d_ff = c.take(N * ff * es);
   w.d_qkv = c.take(N * 3 * d * es);
+  w.d_q = c.take(N * d * es);
   w.d_kv = c.take((Nk > 0 ? Nk : 1) * 2 * d * es);
   w.delta = (float*)c.take((int64_t)B * m->heads * T * 4);
+  w.ln_partial = (float*)c.take(IMT_LN_BWD_WS_FLOATS(d) * 4);
   w.bytes = c.off;
 }
 
@@ -115,30 +124,30 @@ int linear_bwd_input(const Ctx& c, const void* dy, int64_t lddy, int M, int N, i
   return imt_gemm(&a, c.st);
 }
 
-int pick_split_k(int M, int N, int K) {
-  // enough workgroups to cover the 256 CUs about twice, but keep each split >= 256 deep
-  const int tiles = imt_cdiv(M, 128) * imt_cdiv(N, 128);
-  int s = 512 / (tiles > 0 ? tiles : 1);
-  const int smax = K / 256;
-  if (s > smax) s = smax;
-  if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  return s;
-}
-
-// dW[N,K] += dy[M,N]^T x[M,K] ; db[N] += colsum(dy)
-int linear_bwd_params(const Ctx& c, const void* dy, int64_t lddy, const void* x, int64_t ldx, int M, int N, int K, int64_t w_off,
-                      int64_t b_off) {
-  imt_gemm_args a;
-  memset(&a, 0, sizeof(a));
-  a.dtype = c.dtype; a.layout = IMT_TN; a.M = N; a.N = K; a.K = M;
-  a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = c.G(w_off); a.ldc = K; a.c_dtype = IMT_F32; a.alpha = 1.f;
-  a.split_k = pick_split_k(N, K, M);
-  a.accumulate = (a.split_k == 1);
-  RC(imt_gemm(&a, c.st));
-  if (b_off >= 0) RC(imt_colsum(c.dtype, dy, lddy, M, N, c.G(b_off), nullptr, c.st));
-  return IMT_OK;
-}
+// Weight-gradient GEMMs of one layer are collected here and issued as ONE grouped launch at the end of the layer's
+// backward (dW[N,K] += dy[M,N]^T x[M,K] ; db[N] += colsum(dy), fused).
+struct DeferredDW {
+  imt_gemm_args list[8];
+  int n = 0;
+  void add(const Ctx& c, const void* dy, int64_t lddy, const void* x, int64_t ldx, int M, int N, int K, int64_t w_off, int64_t b_off) {
+    imt_gemm_args& a = list[n++];
+    memset(&a, 0, sizeof(a));
+    a.dtype = c.dtype; a.layout = IMT_TN; a.M = N; a.N = K; a.K = M;
+    a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = c.G(w_off); a.ldc = K; a.c_dtype = IMT_F32; a.alpha = 1.f;
+    a.split_k = 1; a.accumulate = 1;
+    a.a_colsum = b_off >= 0 ? c.G(b_off) : nullptr;  // dy is read once for dW and db
+    // used only if the group cannot be formed (ragged token count): about one workgroup per CU via split-K
+    const int tiles = imt_cdiv(N, 128) * imt_cdiv(K, 128);
+    int sk = 1;
+    while (sk < 8 && tiles * sk * 2 <= 256 && M / (sk * 2) >= 512) sk *= 2;
+    if (M % (c.dtype == IMT_BF16 ? 64 : 32) != 0) { a.split_k = sk; a.accumulate = (sk == 1); }
+  }
+  int flush(const Ctx& c) {
+    const int rc = n ? imt_gemm_grouped_tn(list, n, c.st) : IMT_OK;
+    n = 0;
+    return rc;
+  }
+};
 
 uint64_t site_seed(uint64_t base, int layer, int site) { return base + 0x9E3779B97F4A7C15ull * (uint64_t)(layer * 16 + site + 1); }
 
@@ -182,42 +191,40 @@ int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void*
   return IMT_OK;
 }
 
-// backward of the block: dy = grad of w.out ; writes dx (grad of x) ; cross: also d_kv_src (accumulate flag)
-int attn_block_bwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, StackWs& sw, const void* x, int B, int T, const void* kv_src,
-                   int Tk, const MaskSet& ms, bool training, uint64_t seed, int layer, int site0, const void* dy, void* dx,
+// backward of the block: dy = grad of w.out (in sw.d_run or the caller's d_out); writes the gradient of x into
+// sw.d_run; cross: also d_kv_src (accumulate flag).  `slot` selects the dpre/ddrop scratch pair (1 cross, 2 self).
+int attn_block_bwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, StackWs& sw, DeferredDW& dw, int slot, const void* x, int B, int T,
+                   const void* kv_src, int Tk, const MaskSet& ms, bool training, uint64_t seed, int layer, int site0, const void* dy,
                    void* d_kv_src, int accumulate_kv) {
   const int d = c.m->d;
   const int N = B * T;
   const float hp = training ? c.m->hidden_dropout : 0.f, ap = training ? c.m->attn_dropout : 0.f;
-  // LN backward: d_pre (residual path) in sw.d_b ; dropped copy for the dense path in sw.d_c when dropout is on
-  void* d_pre = sw.d_b;
-  void* d_dense = (hp > 0.f) ? sw.d_c : d_pre;
+  void* d_pre = sw.dpre[slot];
+  void* d_dense = (hp > 0.f) ? sw.ddrop[slot] : d_pre;
   RC(imt_layernorm_bwd(c.dtype, dy, w.pre_ln, c.P(p.ln_g), w.mean, w.rstd, d_pre, c.G(p.ln_g), c.G(p.ln_b), N, d, 0.f, 0,
-                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, site0 + 1), c.st));
-  RC(linear_bwd_params(c, d_dense, d, w.ctx, d, N, d, d, p.o_w, p.o_b));
-  // d_ctx -> reuse sw.d_c if free, else sw.d_a (dy may alias d_a: dy is dead after the LN backward above)
-  void* d_ctx = (hp > 0.f) ? sw.d_a : sw.d_c;
-  RC(linear_bwd_input(c, d_dense, d, N, d, p.o_w, d, d_ctx, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0));
+                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, site0 + 1), nullptr, c.st));
+  dw.add(c, d_dense, d, w.ctx, d, N, d, d, p.o_w, p.o_b);
+  RC(linear_bwd_input(c, d_dense, d, N, d, p.o_w, d, sw.d_ctx, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0));
   imt_attn_args a;
   if (!kv_src) {
     attn_args(c, a, B, T, T, w.qkv, 3 * d, offp(w.qkv, d, c.es), 3 * d, offp(w.qkv, 2 * d, c.es), 3 * d, w.ctx, w.lse, ms, ap,
               site_seed(seed, layer, site0));
-    a.dO = d_ctx; a.lddo = d;
+    a.dO = sw.d_ctx; a.lddo = d;
     a.dQ = sw.d_qkv; a.lddq = 3 * d; a.dK = offp(sw.d_qkv, d, c.es); a.lddk = 3 * d; a.dV = offp(sw.d_qkv, 2 * d, c.es); a.lddv = 3 * d;
     a.delta = sw.delta;
     RC(imt_attention_bwd(&a, c.st));
-    RC(linear_bwd_params(c, sw.d_qkv, 3 * d, x, d, N, 3 * d, d, p.qkv_w, p.qkv_b));
-    RC(linear_bwd_input(c, sw.d_qkv, 3 * d, N, 3 * d, p.qkv_w, d, dx, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
+    dw.add(c, sw.d_qkv, 3 * d, x, d, N, 3 * d, d, p.qkv_w, p.qkv_b);
+    RC(linear_bwd_input(c, sw.d_qkv, 3 * d, N, 3 * d, p.qkv_w, d, sw.d_run, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
   } else {
     const int Nk = B * Tk;
     attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, 2 * d, offp(w.kv, d, c.es), 2 * d, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
-    a.dO = d_ctx; a.lddo = d;
-    a.dQ = sw.d_qkv; a.lddq = d; a.dK = sw.d_kv; a.lddk = 2 * d; a.dV = offp(sw.d_kv, d, c.es); a.lddv = 2 * d;
+    a.dO = sw.d_ctx; a.lddo = d;
+    a.dQ = sw.d_q; a.lddq = d; a.dK = sw.d_kv; a.lddk = 2 * d; a.dV = offp(sw.d_kv, d, c.es); a.lddv = 2 * d;
     a.delta = sw.delta;
     RC(imt_attention_bwd(&a, c.st));
-    RC(linear_bwd_params(c, sw.d_qkv, d, x, d, N, d, d, p.qkv_w, p.qkv_b));
-    RC(linear_bwd_params(c, sw.d_kv, 2 * d, kv_src, d, Nk, 2 * d, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d));
-    RC(linear_bwd_input(c, sw.d_qkv, d, N, d, p.qkv_w, d, dx, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
+    dw.add(c, sw.d_q, d, x, d, N, d, d, p.qkv_w, p.qkv_b);
+    dw.add(c, sw.d_kv, 2 * d, kv_src, d, Nk, 2 * d, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d);
+    RC(linear_bwd_input(c, sw.d_q, d, N, d, p.qkv_w, d, sw.d_run, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
     if (d_kv_src)
       RC(linear_bwd_input(c, sw.d_kv, 2 * d, Nk, 2 * d, p.qkv_w + (int64_t)d * d, d, d_kv_src, d, nullptr, 0, nullptr, IMT_AUX_NONE, accumulate_kv));
   }
@@ -233,18 +240,18 @@ int ffn_fwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, const void* x, in
   return IMT_OK;
 }
 
-int ffn_bwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, StackWs& sw, const void* x, int N, bool training, uint64_t seed, int layer,
-            const void* dy, void* dx) {
+int ffn_bwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, StackWs& sw, DeferredDW& dw, const void* x, int N, bool training,
+            uint64_t seed, int layer, const void* dy) {
   const int d = c.m->d, ff = c.m->ff;
   const float hp = training ? c.m->hidden_dropout : 0.f;
-  void* d_pre = sw.d_b;
-  void* d_dense = (hp > 0.f) ? sw.d_c : d_pre;
+  void* d_pre = sw.dpre[0];
+  void* d_dense = (hp > 0.f) ? sw.ddrop[0] : d_pre;
   RC(imt_layernorm_bwd(c.dtype, dy, w.pre_ln2, c.P(p.ln2_g), w.mean2, w.rstd2, d_pre, c.G(p.ln2_g), c.G(p.ln2_b), N, d, 0.f, 0,
-                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, 8), c.st));
-  RC(linear_bwd_params(c, d_dense, d, w.h, ff, N, d, ff, p.ff2_w, p.ff2_b));
+                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, 8), nullptr, c.st));
+  dw.add(c, d_dense, d, w.h, ff, N, d, ff, p.ff2_w, p.ff2_b);
   RC(linear_bwd_input(c, d_dense, d, N, d, p.ff2_w, ff, sw.d_ff, ff, nullptr, 0, w.z, IMT_AUX_DGELU, 0));  // dz
-  RC(linear_bwd_params(c, sw.d_ff, ff, x, d, N, ff, d, p.ff1_w, p.ff1_b));
-  RC(linear_bwd_input(c, sw.d_ff, ff, N, ff, p.ff1_w, d, dx, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
+  dw.add(c, sw.d_ff, ff, x, d, N, ff, d, p.ff1_w, p.ff1_b);
+  RC(linear_bwd_input(c, sw.d_ff, ff, N, ff, p.ff1_w, d, sw.d_run, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
   return IMT_OK;
 }
 
@@ -318,9 +325,10 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   const uint64_t seed = io->dropout_seed;
   const MaskSet self_ms{io->key_mask, io->query_mask, io->mask3d, io->causal};
   const MaskSet cross_ms{io->enc_mask, nullptr, nullptr, 0};
-  // The running gradient w.r.t. the current layer's output lives in w.d_a between layers (and between
-  // segment calls); the first segment reads it from io->d_out.
-  const void* dy = (layer_hi == m->n_layers) ? io->d_out : w.d_a;
+  // The running gradient w.r.t. the current layer's output lives in w.d_run between layers (and between segment
+  // calls); the first segment reads it from io->d_out.
+  const void* dy = (layer_hi == m->n_layers) ? io->d_out : w.d_run;
+  DeferredDW dw;
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const imt_layer_desc& p = m->layers[l];
     LayerWs& L = layers[l];
@@ -329,20 +337,21 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
     const void* x_in = (l == 0) ? w.x0 : (const void*)layers[l - 1].out;
     const void* a_self = L.self_attn.out;
     const void* a_ffn_in = has_cross ? L.cross.out : a_self;
-    RC(ffn_bwd(c, p, L, w, a_ffn_in, N, training, seed, l, dy, w.d_a));
+    RC(ffn_bwd(c, p, L, w, dw, a_ffn_in, N, training, seed, l, dy));
     if (has_cross) {
       const bool first_cross = (l == m->n_layers - 1);
-      RC(attn_block_bwd(c, p.cross_attn, L.cross, w, a_self, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4, w.d_a, w.d_a,
+      RC(attn_block_bwd(c, p.cross_attn, L.cross, w, dw, 1, a_self, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4, w.d_run,
                         io->d_enc_states, first_cross ? 0 : 1));
     }
-    RC(attn_block_bwd(c, p.self_attn, L.self_attn, w, x_in, B, T, nullptr, 0, self_ms, training, seed, l, 0, w.d_a, w.d_a, nullptr, 0));
-    dy = w.d_a;
+    RC(attn_block_bwd(c, p.self_attn, L.self_attn, w, dw, 2, x_in, B, T, nullptr, 0, self_ms, training, seed, l, 0, w.d_run, nullptr, 0));
+    RC(dw.flush(c));  // all 4 (encoder) / 7 (decoder) weight-gradient GEMMs of this layer: one launch
+    dy = w.d_run;
   }
   if (layer_lo == 0) {
     const void* dy0 = (m->n_layers == 0) ? io->d_out : dy;
-    RC(imt_layernorm_bwd(c.dtype, dy0, w.emb_sum, c.P(m->emb_ln_g), w.emb_mean, w.emb_rstd, w.d_b, c.G(m->emb_ln_g), c.G(m->emb_ln_b), N, d,
-                         training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), nullptr, 0.f, 0, c.st));
-    RC(imt_embed_bwd(c.dtype, io->ids, io->pos_ids, io->type_ids, w.d_b, c.G(m->emb_word), c.G(m->emb_pos), c.G(m->emb_type), N, T, d,
+    RC(imt_layernorm_bwd(c.dtype, dy0, w.emb_sum, c.P(m->emb_ln_g), w.emb_mean, w.emb_rstd, w.dpre[0], c.G(m->emb_ln_g), c.G(m->emb_ln_b), N, d,
+                         training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), nullptr, 0.f, 0, nullptr, c.st));
+    RC(imt_embed_bwd(c.dtype, io->ids, io->pos_ids, io->type_ids, w.dpre[0], c.G(m->emb_word), c.G(m->emb_pos), c.G(m->emb_type), N, T, d,
                      m->pad_id, c.st));
   }
   return IMT_OK;

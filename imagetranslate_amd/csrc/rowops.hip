@@ -2,6 +2,7 @@
 // (bias gradients), row gather/scatter (non-pad target row select), casts.
 // One 64-lane wave owns one row; every lane moves 4 consecutive elements per access (8 B bf16 / 16 B fp32),
 // so a wave instruction covers 256 consecutive elements; row statistics are wave reductions.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                      int d, int rows_per_wave, uint32_t y_thresh, float y_inv_keep,
                                                      uint64_t y_seed, T* __restrict__ dx_drop, uint32_t dx_thresh,
-                                                     float dx_inv_keep, uint64_t dx_seed) {
+                                                     float dx_inv_keep, uint64_t dx_seed, float* __restrict__ partial) {
   __shared__ float red[2][ROWS_PER_BLOCK][NCH * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   f32x4 g[NCH], ag[NCH], ab[NCH];
@@ -81,24 +82,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int row_begin = (blockIdx.x * ROWS_PER_BLOCK + w) * rows_per_wave;
+  // software prefetch: the loads of row r+1 are issued before row r is reduced (each wave keeps two rows in flight)
+  f32x4 nx[NCH], nd[NCH];
+  auto preload = [&](int row) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      nx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      nd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d && row < rows) {
+        nx[i] = Vec4<T>::load(x + (int64_t)row * d + c);
+        nd[i] = Vec4<T>::load(dy + (int64_t)row * d + c);
+      }
+    }
+  };
+  preload(row_begin);
   for (int rr = 0; rr < rows_per_wave; ++rr) {
     const int row = row_begin + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NCH], dyv[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { xh[i] = nx[i]; dyv[i] = nd[i]; }
+    if (rr + 1 < rows_per_wave) preload(row + 1);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane * 4 + i * 256;
-      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dyv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < d) {
-        const f32x4 xv = Vec4<T>::load(x + (int64_t)row * d + c);
-        dyv[i] = Vec4<T>::load(dy + (int64_t)row * d + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (y_thresh) dyv[i][e] = dropout_keep(y_seed, (uint64_t)row * d + c + e, y_thresh) ? dyv[i][e] * y_inv_keep : 0.f;
-          xh[i][e] = (xv[e] - mu) * rs;
+          xh[i][e] = (xh[i][e] - mu) * rs;
           const float dg = dyv[i][e] * g[i][e];
           s1 += dg;
           s2 += dg * xh[i][e];
@@ -138,9 +153,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int k = 0; k < ROWS_PER_BLOCK; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+    if (partial) {  // two-stage: plain coalesced stores, summed by ln_bwd_reduce_kernel (no same-address atomics storm)
+      partial[((int64_t)blockIdx.x * 2 + 0) * d + c] = sg;
+      partial[((int64_t)blockIdx.x * 2 + 1) * d + c] = sb;
+    } else {
+      atomicAdd(dgamma + c, sg);
+      atomicAdd(dbeta + c, sb);
+    }
   }
+}
+
+// stage 2: dgamma[c] += sum_b partial[b][0][c] ; dbeta likewise.  grid (ceil(d/256), slices): each thread sums one
+// slice of the block partials (coalesced across threads) and issues one atomic -> `slices` adds per address.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int d,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float sg = 0.f, sb = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    sg += partial[((int64_t)b * 2 + 0) * d + c];
+    sb += partial[((int64_t)b * 2 + 1) * d + c];
+  }
+  if (b1 > b0) { atomicAdd(dgamma + c, sg); atomicAdd(dbeta + c, sb); }
 }
 
 // ------------------------------------------------------------------------------------------- embeddings
@@ -289,17 +325,24 @@ int ln_fwd_launch(const void* x, const void* gamma, const void* beta, void* y, f
 template <typename T, int NCH>
 int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, void* dx,
                   float* dgamma, float* dbeta, int rows, int d, float yp, uint64_t yseed, void* dx_drop, float dxp,
-                  uint64_t dxseed, hipStream_t st) {
-  // aim for ~512 blocks; each wave walks rows_per_wave rows
-  int rpw = imt_cdiv(rows, 512 * ROWS_PER_BLOCK);
+                  uint64_t dxseed, float* partial, hipStream_t st) {
+  // ~256 workgroups: the per-workgroup tail (LDS combine + one fp32 atomic per column) is what costs; measured sweep
+  // on MI355X at rows=8192, d=512: 2048 blocks 57 us, 1024: 33, 512: 23, 256: 22, 128: 30 (profiles/r01_ln_bwd_sweep.txt)
+  int rpw = imt_cdiv(rows, 256 * ROWS_PER_BLOCK);
   if (rpw < 1) rpw = 1;
+  if (const char* e = getenv("IMT_LN_RPW")) rpw = atoi(e) > 0 ? atoi(e) : rpw;  // tuning hook
   const int blocks = imt_cdiv(rows, rpw * ROWS_PER_BLOCK);
   ImtProfScope prof("layernorm_bwd", 0.0, (dx_drop ? 4.0 : 3.0) * rows * d * sizeof(T), st);
   hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
                      (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),
                      yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),
-                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed);
+                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed, partial);
   IMT_CHECK_LAUNCH();
+  if (partial) {
+    ImtProfScope prof2("layernorm_bwd_reduce", 0.0, 8.0 * blocks * d, st);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(imt_cdiv(d, 256), 16), dim3(256), 0, st, partial, blocks, d, dgamma, dbeta);
+    IMT_CHECK_LAUNCH();
+  }
   return IMT_OK;
 }
 
@@ -331,7 +374,7 @@ extern "C" int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, co
 extern "C" int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
                                  float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
-                                 uint64_t dx_dropout_seed, void* stream) {
+                                 uint64_t dx_dropout_seed, float* partial_ws, void* stream) {
   IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "layernorm_bwd: bad dtype");
   IMT_CHECK_ARG(d > 0 && d % 4 == 0, "layernorm_bwd: d must be a positive multiple of 4");
   if (rows <= 0) return IMT_OK;
@@ -339,9 +382,9 @@ extern "C" int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IMT_F32)
     IMT_DISPATCH_NCH(ln_bwd_launch, float, d, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, d, y_dropout_p,
-                     y_dropout_seed, dx_drop, dx_dropout_p, dx_dropout_seed, st);
+                     y_dropout_seed, dx_drop, dx_dropout_p, dx_dropout_seed, partial_ws, st);
   IMT_DISPATCH_NCH(ln_bwd_launch, bf16_t, d, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, d, y_dropout_p,
-                   y_dropout_seed, dx_drop, dx_dropout_p, dx_dropout_seed, st);
+                   y_dropout_seed, dx_drop, dx_dropout_p, dx_dropout_seed, partial_ws, st);
 }
 
 extern "C" int imt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,

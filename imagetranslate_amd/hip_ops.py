@@ -39,7 +39,8 @@ def _rowmajor(t):
 
 
 def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=None, aux_mode=IMT_AUX_NONE,
-         accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0, alpha_dev=None):
+         accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0, alpha_dev=None, a_colsum=None,
+         force_general=False, force_pipeline=False, _launch=True):
     """C = epilogue(op(A) op(B)); see include/imt_hip.h:imt_gemm."""
     _req_cuda(A, B, out, bias, resid, aux)
     if layout == IMT_NT:
@@ -65,8 +66,21 @@ def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=N
     a.aux_mode, a.split_k = aux_mode, split_k
     a.alpha, a.dropout_p, a.dropout_seed = alpha, dropout_p, dropout_seed
     a.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
+    a.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None
+    a.force_general = int(force_general)
+    a.force_pipeline = int(force_pipeline)
+    if not _launch:
+        return a
     L.check(L.load().imt_gemm(ctypes.byref(a), _stream()), "imt_gemm")
     return out
+
+
+def gemm_grouped_tn(problems):
+    """problems: list of dicts(A=dy[K,M], B=x[K,N], out=fp32 grad [M,N], a_colsum=optional) -> one launch."""
+    arr = (L.GemmArgs * len(problems))()
+    for i, pr in enumerate(problems):
+        arr[i] = gemm(pr["A"], pr["B"], IMT_TN, out=pr["out"], accumulate=True, a_colsum=pr.get("a_colsum"), _launch=False)
+    L.check(L.load().imt_gemm_grouped_tn(arr, len(problems), _stream()), "imt_gemm_grouped_tn")
 
 
 def colsum(X, out, scale_dev=None):
@@ -88,14 +102,15 @@ def layernorm_fwd(x, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, y_dropout_p=0.0, y_dropout_seed=0, want_dx_drop=False,
-                  dx_dropout_p=0.0, dx_dropout_seed=0):
+                  dx_dropout_p=0.0, dx_dropout_seed=0, two_stage=False):
     _req_cuda(dy, x, gamma, dgamma, dbeta)
     rows, d = x.shape
     dx = torch.empty_like(x)
     dx_drop = torch.empty_like(x) if want_dx_drop else None
+    ws = torch.empty(1024 * 2 * d, device=x.device, dtype=torch.float32) if two_stage else None
     L.check(L.load().imt_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                        _p(dbeta), rows, d, y_dropout_p, y_dropout_seed, _p(dx_drop), dx_dropout_p,
-                                       dx_dropout_seed, _stream()), "imt_layernorm_bwd")
+                                       dx_dropout_seed, _p(ws), _stream()), "imt_layernorm_bwd")
     return (dx, dx_drop) if want_dx_drop else dx
 
 

@@ -97,8 +97,8 @@ class _FusedXentFn(torch.autograd.Function):
         gw = store.grad[ctx.wo:ctx.wo + V * K].view(V, K)
         n = dlogits.shape[0]
         sk = max(1, min(n // 512, 512 // max(1, ((V + 127) // 128) * ((K + 127) // 128))))
-        O.gemm(dlogits, x, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk, alpha_dev=g)
-        O.colsum(dlogits, store.grad[ctx.bo:ctx.bo + V], scale_dev=g)
+        O.gemm(dlogits, x, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk, alpha_dev=g,
+               a_colsum=store.grad[ctx.bo:ctx.bo + V])  # bias gradient fused: dlogits is read once
         store.attach_grad_views()
         hook = getattr(store, "output_hook", None)
         if hook is not None:

@@ -88,8 +88,17 @@ typedef struct imt_gemm_args {
   float dropout_p;
   uint64_t dropout_seed;
   const float* alpha_dev; /* nullable device scalar multiplied into alpha (upstream loss gradient, no host sync) */
+  float* a_colsum;        /* IMT_TN only, nullable: a_colsum[m] += alpha * sum_k A[k,m]  (bias gradient of the same
+                             nn.Linear, fused into its weight-gradient GEMM: dy is read once) */
+  int32_t force_general;  /* tests / tuning: kernel variant, 0 = auto, 1 = register-staged double buffer (2 blocks/CU),
+                             2 = LDS-DMA 3-stage ring (1 block/CU; needs K a whole number of tiles), 3 = single LDS buffer
+                             + register prefetch (4 blocks/CU) */
+  int32_t force_pipeline; /* reserved */
 } imt_gemm_args;
 int imt_gemm(const imt_gemm_args* a, void* stream);
+/* All weight-gradient GEMMs (IMT_TN, fp32 C += alpha * A^T B, optional a_colsum) of one transformer layer in ONE
+ * launch (HOST array of `count` descriptors).  Problems that cannot be grouped fall back to imt_gemm each. */
+int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* stream);
 
 /* column sums: out[n] += scale * sum_m X[m,n]  -> bias gradients (fp32, accumulated); scale_dev nullable. */
 int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, const float* scale_dev, void* stream);
@@ -106,7 +115,10 @@ int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* b
 int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
                       float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
-                      uint64_t dx_dropout_seed, void* stream);
+                      uint64_t dx_dropout_seed, float* partial_ws, void* stream);
+/* partial_ws (nullable): IMT_LN_BWD_WS_FLOATS(d) floats of scratch; when given, dgamma/dbeta are reduced in two
+ * stages (per-workgroup partials + a small reduce kernel) instead of one fp32 atomic per column per workgroup. */
+#define IMT_LN_BWD_WS_FLOATS(d) (1024 * 2 * (int64_t)(d))
 
 /* ------------------------------------------------------------------ embeddings (HF BertEmbeddings)
  * fwd: out[n,:] = word[ids[n]] + pos[pos_ids ? pos_ids[n] : n % seq_len] + type[type_ids[n]]   (pre-LN sum)

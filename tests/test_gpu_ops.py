@@ -123,6 +123,85 @@ def test_gemm_epilogues(cuda, dtype):
     assert_close(d1[keep], full[keep], tol, "dropout kept values")
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_pipelined_vs_general_kernel(cuda, dtype, layout):
+    """The LDS-DMA pipelined main loop (whole K tiles) and the register-staged general kernel must agree BIT-EXACTLY
+    on integer data, for 2..many K tiles, ragged M/N, strided operand views and split-K."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(11)
+    bk = 64 if dtype == torch.bfloat16 else 32
+    for (M, N, nk, sk) in [(128, 128, 2, 1), (200, 136, 3, 1), (256, 264, 9, 1), (136, 128, 16, 4), (1000, 72, 5, 1)]:
+        K = nk * bk
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        B = torch.randint(-3, 4, (N, K), generator=g).float()
+        A[:, 1] += torch.arange(M).float() % 7
+        ref = A @ B.t()
+        if layout == O.IMT_NT:
+            a_in, b_in = A, B
+        elif layout == O.IMT_NN:
+            a_in, b_in = A, B.t().contiguous()
+        else:
+            a_in, b_in = A.t().contiguous(), B.t().contiguous()
+        if (a_in.shape[1] % 8) or (b_in.shape[1] % 8):
+            continue
+        # embed the operands in wider buffers (strided views, like q/k/v inside the fused qkv buffer)
+        wa = torch.full((a_in.shape[0], a_in.shape[1] + 16), 99.0); wa[:, 8:8 + a_in.shape[1]] = a_in
+        wb = torch.full((b_in.shape[0], b_in.shape[1] + 24), -77.0); wb[:, 16:16 + b_in.shape[1]] = b_in
+        da = wa.to(dtype).to(cuda)[:, 8:8 + a_in.shape[1]]
+        db = wb.to(dtype).to(cuda)[:, 16:16 + b_in.shape[1]]
+        outs = []
+        for force in (2, 1, 3):  # LDS-DMA pipeline, register-staged double buffer, single-buffer high-occupancy
+            out = torch.zeros((M, N), device=cuda, dtype=torch.float32)
+            O.gemm(da, db, layout, out=out, split_k=sk if layout == O.IMT_TN else 1,
+                   accumulate=False, force_general=force)
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], ref), "pipelined kernel wrong: layout %d %s max diff %g" % (
+            layout, (M, N, K), float((outs[0] - ref).abs().max()))
+        assert torch.equal(outs[1], ref), "general kernel wrong"
+        assert torch.equal(outs[2], ref), "single-buffer kernel wrong"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_fused_bias_gradient(cuda, dtype):
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(12)
+    for (tokens, out_f, in_f, sk, force) in [(512, 200, 136, 1, False), (512, 200, 136, 4, False), (300, 264, 72, 1, True),
+                                             (1024, 1000, 128, 2, False)]:
+        dy, dyf = _mk((tokens, out_f), dtype, cuda, 1.0, g)
+        x, xf = _mk((tokens, in_f), dtype, cuda, 1.0, g)
+        gw0 = torch.randn((out_f, in_f), generator=g); gb0 = torch.randn(out_f, generator=g)
+        gw, gb = gw0.clone().to(cuda), gb0.clone().to(cuda)
+        scale = torch.tensor([0.5], device=cuda)
+        O.gemm(dy, x, O.IMT_TN, out=gw, split_k=sk, accumulate=(sk == 1), a_colsum=gb, alpha_dev=scale, force_general=force)
+        tol = 2e-5 if dtype == torch.float32 else 1e-2
+        assert_close(gw, gw0 + 0.5 * dyf.t() @ xf, tol, "dW")
+        assert_close(gb, gb0 + 0.5 * dyf.sum(0), tol, "db (fused colsum)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_grouped_weight_gradients(cuda, dtype):
+    """imt_gemm_grouped_tn: the 4..7 weight-gradient GEMMs of a layer in one launch == the individual results;
+    ragged token counts fall back to individual launches (same answers)."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(13)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    for tokens in (512, 520):  # 520 is not a whole number of K tiles -> fallback path
+        shapes = [(384, 128), (128, 128), (512, 128), (128, 512), (200, 136)]
+        probs, refs = [], []
+        for (out_f, in_f) in shapes:
+            dy, dyf = _mk((tokens, out_f), dtype, cuda, 1.0, g)
+            x, xf = _mk((tokens, in_f), dtype, cuda, 1.0, g)
+            gw0 = torch.randn((out_f, in_f), generator=g); gb0 = torch.randn(out_f, generator=g)
+            gw, gb = gw0.clone().to(cuda), gb0.clone().to(cuda)
+            probs.append(dict(A=dy, B=x, out=gw, a_colsum=gb))
+            refs.append((gw0 + dyf.t() @ xf, gb0 + dyf.sum(0)))
+        O.gemm_grouped_tn(probs)
+        for pr, (rw, rb) in zip(probs, refs):
+            assert_close(pr["out"], rw, tol, "grouped dW (tokens=%d)" % tokens)
+            assert_close(pr["a_colsum"], rb, tol, "grouped db (tokens=%d)" % tokens)
+
+
 def test_gemm_bad_args(cuda):
     from imagetranslate_amd import hip_ops as O
     from imagetranslate_amd._lib import ImtError
@@ -160,8 +239,8 @@ def test_layernorm(cuda, dtype, d):
     assert_close(dx, xr.grad, tol * 2, "ln dx")
     assert_close(dgamma, gr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dgamma")
     assert_close(dbeta, br.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dbeta")
-    # accumulation semantics: second call doubles the parameter grads
-    O.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta)
+    # accumulation semantics: second call (two-stage reduction path) doubles the parameter grads
+    O.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, two_stage=True)
     assert_close(dgamma, 2 * gr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dgamma accum")
 
 

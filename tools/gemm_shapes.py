@@ -41,10 +41,15 @@ def main():
         (O.IMT_NN, T, ff, d, "ffn2 dx"), (O.IMT_NN, 8128, d, V, "vocab dx"),
     ]
     for lay, M, N, K, name in shapes:
-        us, tf = bench(lay, M, N, K)
-        print("%-14s %s M=%5d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, names[lay], M, N, K, us, tf), flush=True)
+        res = []
+        for variant in (1, 2, 3, 4):
+            if variant in (2, 4) and K % 64:
+                res.append((0.0, 0.0)); continue
+            res.append(bench(lay, M, N, K, force_general=variant))
+        print("%-14s %s M=%5d N=%5d K=%5d  dbuf %6.1f us %5.0f TF | dma3 %6.1f us %5.0f TF | sbuf %6.1f us %5.0f TF | dma4 %6.1f us %5.0f TF" % (
+            name, names[lay], M, N, K, res[0][0], res[0][1], res[1][0], res[1][1], res[2][0], res[2][1], res[3][0], res[3][1]), flush=True)
     for (M, N, name) in [(3 * d, d, "qkv dW"), (d, d, "attn-out dW"), (ff, d, "ffn1 dW"), (d, ff, "ffn2 dW")]:
-        for sk in (1, 2, 4, 8, 16, 32):
+        for sk in (1, 4):
             us, tf = bench(O.IMT_TN, M, N, T, split_k=sk)
             print("%-14s TN M=%5d N=%5d K=%5d split_k=%2d %8.1f us  %7.1f TF/s" % (name, M, N, T, sk, us, tf), flush=True)
     for sk in (1, 2, 4):
