@@ -114,8 +114,8 @@ def profile_pass(step_fn, steps=2):
     for _ in range(steps):
         step_fn()
     torch.cuda.synchronize()
-    rows = (L.ProfRow * 64)()
-    n = lib.imt_prof_report(rows, 64)
+    rows = (L.ProfRow * 256)()
+    n = lib.imt_prof_report(rows, 256)
     lib.imt_prof_enable(0)
     out = []
     for i in range(n):
@@ -217,9 +217,9 @@ def main():
         print("[bench] gpu: %.1f tokens/s, %.3f ms/step" % (value, ms_per_step), file=sys.stderr, flush=True)
         if args.breakdown:
             tot = sum(r["ms"] for r in rows)
-            print("%-22s %8s %10s %9s %9s" % ("kernel", "launches", "ms/step", "TFLOP/s", "GB/s"), file=sys.stderr)
+            print("%-40s %8s %10s %9s %9s" % ("kernel", "launches", "ms/step", "TFLOP/s", "GB/s"), file=sys.stderr)
             for r in rows:
-                print("%-22s %8d %10.3f %9.1f %9.1f" % (r["kind"], r["launches"], r["ms"], r["flops"] / (r["ms"] * 1e9 + 1e-30),
+                print("%-40s %8d %10.3f %9.1f %9.1f" % (r["kind"], r["launches"], r["ms"], r["flops"] / (r["ms"] * 1e9 + 1e-30),
                                                         r["bytes"] / (r["ms"] * 1e6 + 1e-30)), file=sys.stderr)
             print("sum of kernel time %.3f ms / step (instrumented pass)" % tot, file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline(c) if (world == 1 and not args.no_cpu_baseline) else None

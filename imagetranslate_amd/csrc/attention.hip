@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char Vs[64 * RB];
   __shared__ uint8_t kmask_s[64];
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int nqt = (p.Tq + 63) / 64;
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);  // batch-major: XCD x owns batches [x*B/8, (x+1)*B/8)
+  const int b = lid / (p.H * nqt), h = (lid / nqt) % p.H, tile_x = lid % nqt;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = tile_x * 64 + wave * 16;
   const int i = q0 + r;  // this lane's query row
   const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
   const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
@@ -214,9 +216,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) char Vs[64 * RB];
   __shared__ uint8_t kmask_s[64];
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int nqt = (p.Tq + 63) / 64;
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);  // batch-major: XCD x owns batches [x*B/8, (x+1)*B/8)
+  const int b = lid / (p.H * nqt), h = (lid / nqt) % p.H, tile_x = lid % nqt;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = tile_x * 64 + wave * 16;
   const int i = q0 + r;
   const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
   const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
@@ -308,9 +312,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
   __shared__ float lse_s[64], delta_s[64];
   __shared__ uint8_t qmask_s[64];
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int nkt0 = (p.Tk + 63) / 64;
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);
+  const int b = lid / (p.H * nkt0), h = (lid / nkt0) % p.H, tile_x = lid % nkt0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int k0 = tile_x * 64 + wave * 16;
   const int j = k0 + r;  // this lane's key
   const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
   const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
@@ -423,7 +429,7 @@ AttnP make_params(const imt_attn_args* a) {
 }
 
 template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
-  dim3 grid(imt_cdiv(p.Tq, 64), p.H, p.B);
+  dim3 grid(imt_cdiv(p.Tq, 64) * p.H * p.B);
   const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
   const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
   ImtProfScope prof(sizeof(T) == 2 ? "attn_fwd_bf16" : "attn_fwd_f32", 4.0 * work, io, st);
@@ -436,12 +442,12 @@ template <typename T, int DH> int bwd_launch(const AttnP& p, hipStream_t st) {
   const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
   {
     ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dq_bf16" : "attn_bwd_dq_f32", 6.0 * work, io * 1.5, st);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64), p.H, p.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64) * p.H * p.B), dim3(256), 0, st, p);
     IMT_CHECK_LAUNCH();
   }
   {
     ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dkdv_bf16" : "attn_bwd_dkdv_f32", 8.0 * work, io * 1.5, st);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH>), dim3(imt_cdiv(p.Tk, 64), p.H, p.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH>), dim3(imt_cdiv(p.Tk, 64) * p.H * p.B), dim3(256), 0, st, p);
     IMT_CHECK_LAUNCH();
   }
   return IMT_OK;

@@ -43,6 +43,7 @@ static inline int imt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- optional launch profiler (core.hip)
 bool imt_prof_enabled();
+const char* imt_prof_intern(const char* kind, int M, int N, int K);
 void* imt_prof_begin_launch(const char* kind, double flops, double bytes, hipStream_t st);
 void imt_prof_end_launch(void* tok, hipStream_t st);
 struct ImtProfScope {
@@ -51,6 +52,16 @@ struct ImtProfScope {
       : tok(imt_prof_enabled() ? imt_prof_begin_launch(kind, flops, bytes, s) : nullptr), st(s) {}
   ~ImtProfScope() { if (tok) imt_prof_end_launch(tok, st); }
 };
+
+// ---------------------------------------------------------------- XCD-affine work distribution
+// Workgroup b runs on XCD b % 8 (measured on MI355X, tools/probe_xcc.hip: strict round-robin, block 0 on XCC 0 in
+// every launch).  Every kernel therefore maps hardware block id -> logical work item with the SAME bijection
+// below: XCD x owns the x-th contiguous eighth of the work (token rows), so what one kernel writes stays in the L2
+// of the XCD whose workgroups read it in the next kernel (tools/probe_l2.hip).  Placement affects speed only.
+IMT_DEVICE int imt_xcd_block(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 
 // ---------------------------------------------------------------- scalar conversions
 template <typename T> IMT_DEVICE float to_f32(T v);
@@ -93,11 +104,32 @@ IMT_DEVICE float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- math
-IMT_DEVICE float gelu_erf(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+// exact-erf GELU (src/lm_config.py:7 "gelu" == F.gelu) evaluated with the Abramowitz-Stegun 7.1.26 rational form:
+//   erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2),  t = 1/(1 + p x),  x >= 0      |error| <= 1.5e-7 (absolute)
+// i.e. below fp32 round-off of the surrounding sums and 3 orders under the 1e-4 parity bar, at ~1/4 of the VALU cost
+// of libm's erff (the GELU / GELU' epilogues of the FFN GEMMs were costing as much as their MFMA main loops).
+// The same exponential serves the Gaussian pdf of the derivative: exp(-x^2) with x = z/sqrt(2) is exp(-z^2/2).
+IMT_DEVICE void erf_and_gauss(float z, float& erf_v, float& gauss) {
+  const float x = fabsf(z) * 0.70710678118654752440f;
+  const float e = __expf(-x * x);
+  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float y = 1.0f - p * t * e;
+  erf_v = copysignf(y, z);
+  gauss = e;
+}
+IMT_DEVICE float gelu_erf(float z) {
+  float er, ga;
+  erf_and_gauss(z, er, ga);
+  return 0.5f * z * (1.0f + er);
+}
 IMT_DEVICE float gelu_erf_grad(float z) {
-  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
-  return cdf + z * pdf;
+  float er, ga;
+  erf_and_gauss(z, er, ga);
+  return 0.5f * (1.0f + er) + z * 0.39894228040143267794f * ga;
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
@@ -107,9 +139,9 @@ IMT_DEVICE uint32_t mix32(uint32_t x) {
   return x;
 }
 IMT_DEVICE bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh /* p * 2^32 */) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = mix32(lo ^ (uint32_t)seed) ^ mix32(hi + (uint32_t)(seed >> 32) + 0x9e3779b9U);
-  h = mix32(h);
+  // two rounds of a 32-bit finaliser over (index, seed): ~12 integer ops per element
+  uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
+  h = mix32(h + (uint32_t)(idx >> 32) * 0x9e3779b9U + (uint32_t)(seed >> 32));
   return h >= thresh;
 }
 static inline uint32_t dropout_thresh(float p) {

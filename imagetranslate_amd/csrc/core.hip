@@ -41,6 +41,17 @@ hipEvent_t take_event() {
 
 bool imt_prof_enabled() { return g_prof_on; }
 
+// "kind MxNxK" strings with process lifetime (profiling only)
+const char* imt_prof_intern(const char* kind, int M, int N, int K) {
+  static std::map<std::string, std::string*> table;
+  char buf[96];
+  snprintf(buf, sizeof(buf), "%s %dx%dx%d", kind, M, N, K);
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = table.find(buf);
+  if (it == table.end()) it = table.emplace(buf, new std::string(buf)).first;
+  return it->second->c_str();
+}
+
 void* imt_prof_begin_launch(const char* kind, double flops, double bytes, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_prof_on) return nullptr;

@@ -15,6 +15,7 @@
 //                      applied to the per-lane SOURCE address (the DMA destination is lane-linear).  Used whenever
 //                      the K extent of a block is a whole number of tiles.
 //   gemm_kernel      : register-staged double buffer with predicated (zero-filling) loads: ragged K / tiny K.
+#include <stdlib.h>
 #include "mma.hpp"
 
 namespace {
@@ -102,6 +103,7 @@ struct EpiParams {
   float alpha; const float* alpha_dev;
   float inv_keep; uint32_t drop_thresh; uint64_t seed;
   float* a_colsum;  // TN only: a_colsum[m] += alpha * sum_k A[k][m]   (bias gradient fused into the dW GEMM)
+  int dbg;          // tuning only (tools/gemm_shapes.py): bit0 skip the tile products, bit1 skip the in-loop DMA
 };
 
 // ------------------------------------------------------------------------------------------------ tile product
@@ -167,23 +169,37 @@ template <typename T> struct ColSum {
 };
 
 // ------------------------------------------------------------------------------------------------ epilogue
-// lane owns C[m = m0+wm+16i+lr][n = n0+wn+16j+4lg .. +3]
+// The accumulators are C^T fragments (lane (lr,lg) of wave (wm,wn) owns C[m = wm+16i+lr][n = wn+16j+4lg..+3]): stored
+// directly they would touch 16 rows x 32 bytes per instruction.  Instead the block restages its tile through LDS in
+// two passes of 64 rows (fp32, 32 KiB, 16-byte groups XOR-swizzled by row) so that EVERY global access of the epilogue
+// (bias, residual, GELU aux, C) is a 16-B-per-lane (8 B for bf16 stores) access with 32 consecutive lanes per row.
+IMT_DEVICE int epi_off(int row, int c4) { return row * 512 + ((c4 ^ (row & 31)) << 4); }
+
 template <typename T>
-IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep, float alpha) {
+IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
+                         float alpha) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* resid = reinterpret_cast<const T*>(ep.resid);
   T* aux = reinterpret_cast<T*>(ep.aux);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm + 16 * i + lr;
-    if (m >= M) continue;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();  // previous users of smem (K loop / previous pass) are done
+    if (wm == 64 * pass) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn + 16 * j + 4 * lg;
-      if (n >= N) continue;
-      f32x4 v = acc[i][j] * alpha;
-      const bool full = (n + 3 < N);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(smem + epi_off(16 * i + lr, (wn + 16 * j + 4 * lg) >> 2)) = acc[i][j] * alpha;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+      const int idx = gq * NTHREADS + threadIdx.x;
+      const int row = idx >> 5, c4 = idx & 31;
+      const int m = m0 + 64 * pass + row, n = n0 + 4 * c4;
+      if (m >= M || n >= N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(smem + epi_off(row, c4));
       if (ep.atomic) {
         float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
 #pragma unroll
@@ -191,14 +207,14 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], int m0, int n0, int wm, int w
           if (n + e < N) atomicAdd(c + e, v[e]);
         continue;
       }
-      if (full) {
+      if (n + 3 < N) {
         if (bias) v += Vec4<T>::load(bias + n);
         if (ep.aux_mode == IMT_AUX_GELU_FWD) {
           Vec4<T>::store(aux + (int64_t)m * ep.ldaux + n, v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         } else if (ep.aux_mode == IMT_AUX_DGELU) {
-          f32x4 z = Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
+          const f32x4 z = Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
         }
@@ -251,9 +267,7 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], int m0, int n0, int wm, int w
 IMT_DEVICE void tile_origin(int M, int N, int& m0, int& n0) {
   const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
   const int nwg = nbx * nby;
-  int bid = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int bid = imt_xcd_block(blockIdx.x, nwg);
   m0 = (bid / nbx) * BM;
   n0 = (bid % nbx) * BN;
 }
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const T* __restrict__ A,
     __syncthreads();
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
-  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, alpha);
+  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha);
   if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem, ep.a_colsum, m0, M, alpha);
 }
 
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_sb_kernel(const T* __restric
     __syncthreads();
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
-  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, alpha);
+  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha);
   if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem, ep.a_colsum, m0, M, alpha);
 }
 
@@ -410,18 +424,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict
     else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    if (t + NSTG - 1 < nt) {
+    if (t + NSTG - 1 < nt && !(ep.dbg & 2)) {
       const int nxt = (cur == 0) ? NSTG - 1 : cur - 1;  // (cur + NSTG - 1) % NSTG
       da.issue(smem + nxt * STAGE_BYTES, ktile(t + NSTG - 1));
       db.issue(smem + nxt * STAGE_BYTES + TILE_BYTES, ktile(t + NSTG - 1));
     }
     const char* ta = smem + cur * STAGE_BYTES;
-    compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
+    if (!(ep.dbg & 1)) compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
     if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
     cur = (cur + 1 == NSTG) ? 0 : cur + 1;
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
-  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, alpha);
+  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha);
   if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem, ep.a_colsum, m0, M, alpha);
 }
 
@@ -488,8 +502,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_grouped_tn_kernel(GroupArgs g) 
   ep.C = P.C; ep.ldc = P.ldc; ep.c_f32 = 1; ep.accumulate = 1;
   ep.bias = nullptr; ep.resid = nullptr; ep.ldr = 0; ep.aux = nullptr; ep.ldaux = 0; ep.aux_mode = IMT_AUX_NONE;
   ep.atomic = 0; ep.alpha = g.alpha; ep.alpha_dev = nullptr; ep.inv_keep = 1.f; ep.drop_thresh = 0; ep.seed = 0;
-  ep.a_colsum = P.a_colsum;
-  epilogue<T>(acc, m0, n0, wm, wn, M, N, ep, g.alpha);
+  ep.a_colsum = P.a_colsum; ep.dbg = 0;
+  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
   if (do_colsum) cs.flush(smem, P.a_colsum, m0, M, g.alpha);
 }
 
@@ -512,7 +526,9 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
   }
   static const char* const kinds[2][3] = {{"gemm_f32_nt", "gemm_f32_nn", "gemm_f32_tn"}, {"gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn"}};
   const double es = sizeof(T), esc = ep.c_f32 ? 4.0 : es;
-  ImtProfScope prof(kinds[sizeof(T) == 2][LAYOUT], 2.0 * a->M * a->N * a->K,
+  const char* kind = kinds[sizeof(T) == 2][LAYOUT];
+  if (imt_prof_enabled() && getenv("IMT_PROF_SHAPES")) kind = imt_prof_intern(kind, a->M, a->N, a->K);
+  ImtProfScope prof(kind, 2.0 * a->M * a->N * a->K,
                     ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * esc, st);
   const T* A = reinterpret_cast<const T*>(a->A);
   const T* B = reinterpret_cast<const T*>(a->B);
@@ -580,10 +596,11 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   const int64_t nblocks = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN) * splits;
   // kernel variant: 1 = register-staged double buffer (2 blocks/CU), 2 = LDS-DMA 3-stage ring (1 block/CU),
   // 3 = single buffer + register prefetch (4 blocks/CU).  a->force_general carries a variant code for tests/tuning.
-  int variant = a->force_general;
+  int variant = a->force_general % 100;
+  const int dbg = a->force_general / 100;
   // measured on MI355X (profiles/r01_v3_gemm_shapes.txt): about one wave of blocks -> the LDS-DMA ring (its long
   // steady state wins when K >= 1024, a tie otherwise); larger grids -> three single-buffer blocks per CU.
-  if (variant == 0) variant = (pipe_ok && nblocks <= 320) ? 2 : (a->layout == IMT_TN ? 1 : 3);
+  if (variant == 0) variant = (a->layout == IMT_TN) ? 1 : 3;  // measured best after the LDS-staged epilogue (profiles/r01_v4_gemm_shapes.txt)
   if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;
   EpiParams ep;
   ep.C = a->C; ep.ldc = a->ldc; ep.c_f32 = c_f32; ep.accumulate = a->accumulate;
@@ -595,6 +612,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   ep.inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
   ep.seed = a->dropout_seed;
   ep.a_colsum = a->a_colsum;
+  ep.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == IMT_F32) return dispatch<float>(a, ep, splits, kps, variant, st);
   return dispatch<bf16_t>(a, ep, splits, kps, variant, st);

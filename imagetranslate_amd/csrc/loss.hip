@@ -46,7 +46,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const T* __restrict__ logits, int64_t ld, float* __restrict__ lp,
                                                               int64_t ldlp, float* __restrict__ lse_out, int V) {
   __shared__ float red[4];
-  const int64_t row = blockIdx.x;
+  const int64_t row = imt_xcd_block(blockIdx.x, gridDim.x);
   const T* z = logits + row * ld;
   float mx, se, sz;
   row_stats<T>(z, V, red, mx, se, sz);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
                                                               const float* __restrict__ lp, int64_t ldlp,
                                                               TO* __restrict__ dlogits, int64_t ld, int V) {
   __shared__ float red[4];
-  const int64_t row = blockIdx.x;
+  const int64_t row = imt_xcd_block(blockIdx.x, gridDim.x);
   const float* g = dlp + row * lddlp;
   const float* l = lp + row * ldlp;
   float s = 0.f;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void smoothed_nll_fwd_kernel(const float* __re
                                                                const int64_t* __restrict__ target, float* __restrict__ loss,
                                                                int V, float eps, int64_t ignore_index) {
   __shared__ float red[4];
-  const int64_t row = blockIdx.x;
+  const int64_t row = imt_xcd_block(blockIdx.x, gridDim.x);
   const int64_t t = target[row];
   const float* l = lp + row * ldlp;
   float s = 0.f;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void smoothed_nll_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void smoothed_nll_bwd_kernel(const float* __restrict__ dloss, const int64_t* __restrict__ target,
                                                                float* __restrict__ dlp, int64_t lddlp, int V, float eps,
                                                                int64_t ignore_index) {
-  const int64_t row = blockIdx.x;
+  const int64_t row = imt_xcd_block(blockIdx.x, gridDim.x);
   const int64_t t = target[row];
   const float g = (t == ignore_index) ? 0.f : dloss[row];
   const float base = -g * (eps / (float)V);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void xent_fused_kernel(T* __restrict__ logits,
                                                          float* __restrict__ loss_rows, int V, float eps, int64_t ignore_index,
                                                          float grad_scale) {
   __shared__ float red[4];
-  const int64_t row = blockIdx.x;
+  const int64_t row = imt_xcd_block(blockIdx.x, gridDim.x);
   T* z = logits + row * ld;
   const int64_t t = target[row];
   const bool ignored = (t == ignore_index);

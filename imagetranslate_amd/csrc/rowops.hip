@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      int rows, int d, float eps, uint32_t thresh, float inv_keep,
                                                      uint64_t seed) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int row = imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* xr = x + (int64_t)row * d;
   f32x4 v[NCH];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int row_begin = (blockIdx.x * ROWS_PER_BLOCK + w) * rows_per_wave;
+  const int row_begin = (imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + w) * rows_per_wave;
   // software prefetch: the loads of row r+1 are issued before row r is reduced (each wave keeps two rows in flight)
   f32x4 nx[NCH], nd[NCH];
   auto preload = [&](int row) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         T* __restrict__ out, int n_tokens, int seq_len, int d, int vocab,
                                                         int max_pos, int n_types) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int n = imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (n >= n_tokens) return;
   int64_t wi = ids[n];
   int64_t pi = pos_ids ? pos_ids[n] : (int64_t)(n % seq_len);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         float* __restrict__ dword, float* __restrict__ dpos,
                                                         float* __restrict__ dtype_tab, int n_tokens, int seq_len, int d,
                                                         int64_t pad_id, int tokb) {
-  const int n0 = blockIdx.x * tokb;
+  const int n0 = imt_xcd_block(blockIdx.x, gridDim.x) * tokb;
   const int n1 = min(n_tokens, n0 + tokb);
   for (int c = threadIdx.x; c < d; c += 256) {
     float tacc[NT_REG];
@@ -273,7 +273,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, int64_t ldx, const int32_t* __restrict__ idx,
                                                           T* __restrict__ out, int64_t ldo, int n_sel, int d, int scatter) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int r = imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (r >= n_sel) return;
   const int64_t src = scatter ? (int64_t)r : (int64_t)idx[r];
   const int64_t dst = scatter ? (int64_t)idx[r] : (int64_t)r;
