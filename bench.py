@@ -69,7 +69,7 @@ def build_model(c, dtype, device):
     return m.to(device)
 
 
-def cpu_baseline(c, seconds_budget=25.0):
+def cpu_baseline(c, seconds_budget=15.0):
     """Reference-equivalent CPU path (this repo's oracle, kind 'port') timed on the host cores on a bounded sample
     of the same workload: the C1 model with a batch of 8 of the 64 sentences, full train step."""
     from oracle import reference_model as R
@@ -81,7 +81,7 @@ def cpu_baseline(c, seconds_budget=25.0):
     cores = max(1, min(16, cores))
     torch.set_num_threads(cores)
     print("[bench] cpu_baseline: oracle train step on %d host threads ..." % cores, file=sys.stderr, flush=True)
-    Bs = max(1, c["B"] // 16)
+    Bs = max(1, c["B"] // 4)
     tp = R.SyntheticTextProcessor(c["V"])
     torch.manual_seed(1234)
     m = R.Seq2Seq(tp, lang_dec=False, enc_layer=c["enc"], dec_layer=c["dec"], embed_dim=c["d"], intermediate_dim=c["ff"],
@@ -94,7 +94,7 @@ def cpu_baseline(c, seconds_budget=25.0):
     R.train_step(m, opt, crit, b)  # warm-up
     print("[bench] cpu_baseline: warm-up step %.1f s" % (time.time() - tw), file=sys.stderr, flush=True)
     t0, n, toks = time.time(), 0, 0
-    while n < 3 and (time.time() - t0) < seconds_budget:
+    while n < 8 and (time.time() - t0) < seconds_budget:
         _, nt = R.train_step(m, opt, crit, b)
         toks += nt
         n += 1
@@ -183,7 +183,14 @@ def main():
         elapsed = float(t)
     loss_val = float(loss.detach())
 
-    rows = profile_pass(step) if rank == 0 else []
+    # instrumented pass: EVERY rank runs the same extra steps (they contain collectives); only rank 0 records events
+    if rank == 0:
+        rows = profile_pass(step)
+    else:
+        rows = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
 

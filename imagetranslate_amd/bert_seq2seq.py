@@ -231,7 +231,9 @@ class _Pretrained(nn.Module):
         pos_ids = None if pos_ids is None else pos_ids.to(dev).contiguous()
         u8 = lambda m: None if m is None else m.to(device=dev, dtype=torch.uint8).contiguous()
         anchor = store.anchor() if torch.is_grad_enabled() else None
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.training else 0
+        # dropout seed of this forward (the backward regenerates the same masks from it); tests pin it
+        fixed = getattr(self, "_imt_dropout_seed", None)
+        seed = (int(fixed) if fixed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())) if self.training else 0
         return _StackFn.apply(anchor, enc_states, self, store, dtype, ids, type_ids, pos_ids, u8(key_mask), u8(query_mask),
                               u8(mask3d), bool(causal), u8(enc_mask), bool(self.training), seed)
 

@@ -72,9 +72,12 @@ template <typename T, bool KCONTIG> struct Dma : TileGeom<T, KCONTIG> {
   __amdgpu_buffer_rsrc_t rsrc;
   int voff[4];    // byte offset of this lane's chunk for k0 = 0
   int kadv;       // byte advance per K tile
-  IMT_DEVICE void init(const T* base, int64_t ld, int64_t valid_bytes, int row0, int kbeg) {
+  int wv;         // which quarter of the tile's 16 pieces this wave issues
+  IMT_DEVICE void init(const T* base, int64_t ld, int64_t valid_bytes, int row0, int kbeg, int wave = -1) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)valid_bytes, 0x00020000);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave < 0) wave = threadIdx.x >> 6;
+    wv = wave;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = 64 * (4 * i + wave) + lane;
@@ -86,7 +89,7 @@ template <typename T, bool KCONTIG> struct Dma : TileGeom<T, KCONTIG> {
     kadv = KCONTIG ? 128 : (int)(G::BK * ld * (int64_t)sizeof(T));
   }
   IMT_DEVICE void issue(char* tile, int t) const {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (4 * i + wave) * 1024), 16,
@@ -152,15 +155,17 @@ template <typename T> struct ColSum {
     }
   }
   // reduce over the threads that share a chunk column, then one atomic per column
-  IMT_DEVICE void flush(char* smem, float* out, int m0, int M, float alpha) {
+  IMT_DEVICE void flush(char* smem, float* out, int m0, int M, float alpha, bool active = true) {
     constexpr int RSTEP = NTHREADS / G::CPR;
     float* red = reinterpret_cast<float*>(smem);  // [RSTEP][128]
     const int c = threadIdx.x % G::CPR, r0 = threadIdx.x / G::CPR;
     __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) red[r0 * 128 + c * EPC + e] = s[e];
+      for (int e = 0; e < EPC; ++e) red[r0 * 128 + c * EPC + e] = s[e];
+    }
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (active && threadIdx.x < 128) {
       float t = 0.f;
       for (int j = 0; j < RSTEP; ++j) t += red[j * 128 + threadIdx.x];
       if (m0 + (int)threadIdx.x < M) atomicAdd(out + m0 + threadIdx.x, t * alpha);
@@ -177,7 +182,7 @@ IMT_DEVICE int epi_off(int row, int c4) { return row * 512 + ((c4 ^ (row & 31)) 
 
 template <typename T>
 IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
-                         float alpha) {
+                         float alpha, bool active = true) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* resid = reinterpret_cast<const T*>(ep.resid);
@@ -185,7 +190,7 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();  // previous users of smem (K loop / previous pass) are done
-    if (wm == 64 * pass) {
+    if (active && wm == 64 * pass) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -193,6 +198,7 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
           *reinterpret_cast<f32x4*>(smem + epi_off(16 * i + lr, (wn + 16 * j + 4 * lg) >> 2)) = acc[i][j] * alpha;
     }
     __syncthreads();
+    if (!active) continue;
 #pragma unroll
     for (int gq = 0; gq < 8; ++gq) {
       const int idx = gq * NTHREADS + threadIdx.x;
@@ -440,6 +446,97 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict
 }
 
 
+// ------------------------------------------------------------------------------------------------ persistent wave-specialised kernel
+// The main GEMM loop of the path when K is a whole number of tiles: 512 threads, waves 0-3 multiply (64x64 each),
+// waves 4-7 stream the operand tiles by LDS-DMA into a 4-stage ring and run AHEAD ACROSS OUTPUT TILES (one workgroup
+// per CU walks tiles b, b+grid, ...), so neither the DMA issue cost nor the first-tile latency nor the epilogue of a
+// tile stalls the MFMA waves of the next one.  The epilogue restages through its own 32 KiB (ring 128 KiB + 32 KiB
+// = the CU's whole 160 KiB).  Producers keep their own counted vmcnt (only DMA), consumers' epilogue loads/stores
+// have theirs; the only coupling is one raw s_barrier per K tile plus the epilogue's four.
+constexpr int WS_NST = 4;
+constexpr int WS_THREADS = 512;
+constexpr int WS_LDS = WS_NST * STAGE_BYTES + 32768;
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict__ A, int64_t lda, int64_t a_bytes,
+                                                             const T* __restrict__ B, int64_t ldb, int64_t b_bytes, int M, int N,
+                                                             int K, EpiParams ep) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  constexpr int BK = TileGeom<T, A_KC>::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* epi = smem + WS_NST * STAGE_BYTES;
+  const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+  const int tiles = nbx * nby;
+  const int nt = K / BK;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool consumer = wave < 4;
+  const int my_tiles = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const bool colsum_kernel = (LAYOUT == IMT_TN) && ep.a_colsum;
+
+  if (!consumer) {
+    // ------------------------------------------------------------ producers: flat stream of (tile, k) steps
+    Dma<T, A_KC> da; Dma<T, B_KC> db;
+    const int total = my_tiles * nt;
+    int iq = 0, tq = 0;  // tile / k index of the NEXT step to issue
+    auto issue_next = [&](int slot) {
+      if (tq == 0) {
+        const int lt = imt_xcd_block(blockIdx.x + iq * gridDim.x, tiles);
+        da.init(A, lda, a_bytes, (lt / nbx) * BM, 0, wave - 4);
+        db.init(B, ldb, b_bytes, (lt % nbx) * BN, 0, wave - 4);
+      }
+      da.issue(smem + slot * STAGE_BYTES, tq);
+      db.issue(smem + slot * STAGE_BYTES + TILE_BYTES, tq);
+      if (++tq == nt) { tq = 0; ++iq; }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int s0 = 0; s0 < WS_NST - 1; ++s0)
+      if (issued < total) { issue_next(s0); ++issued; }
+    int cur = 0, t = 0;
+    for (int q = 0; q < total; ++q) {
+      const int newer = issued - 1 - q;  // steps issued after step q (0 .. WS_NST-2)
+      if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      if (issued < total) { issue_next(cur == 0 ? WS_NST - 1 : cur - 1); ++issued; }
+      cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
+      if (++t == nt) {
+        t = 0;
+        // the consumers' epilogue: 2 passes x 2 barriers (+2 for the fused column sums)
+        asm volatile("s_barrier\n\ts_barrier\n\ts_barrier\n\ts_barrier" ::: "memory");
+        if (colsum_kernel) asm volatile("s_barrier\n\ts_barrier" ::: "memory");
+      }
+    }
+  } else {
+    // ------------------------------------------------------------ consumers
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+    int cur = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+      const int lt = imt_xcd_block(blockIdx.x + i * gridDim.x, tiles);
+      const int m0 = (lt / nbx) * BM, n0 = (lt % nbx) * BN;
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ColSum<T> cs;
+      cs.clear();
+      const bool do_colsum = colsum_kernel && n0 == 0;
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_barrier" ::: "memory");
+        const char* ta = smem + cur * STAGE_BYTES;
+        compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
+        if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
+        cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
+      }
+      epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
+      if (colsum_kernel) cs.flush(epi, ep.a_colsum, m0, M, alpha, do_colsum);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ grouped weight gradients
 // All weight-gradient GEMMs of one transformer layer (dW = dy^T x, K = tokens) in ONE launch: each has only 16-64
 // output tiles, so separately they either idle most CUs or need split-K atomics; together they are ~one tile per
@@ -452,8 +549,17 @@ struct GroupProblem {
 };
 struct GroupArgs { int count; int total_tiles; float alpha; int pad; GroupProblem p[MAX_GROUP]; };
 
+// Wave-specialised: waves 0-3 multiply (one per SIMD), waves 4-7 only issue the LDS-DMA of the tiles ahead.  Issuing
+// a 1-KiB DMA piece costs a wave ~100-200 cycles (MI355X_MICROARCH "LDS-DMA piece issue cost"); done by the MFMA waves
+// themselves it serialises with their tile products (measured: loads-only 35 us + mfma-only 35 us -> 47 us, not
+// max()), done by partner waves on the same SIMDs it overlaps.  One raw s_barrier per K tile: producers first wait
+// (counted vmcnt) for THEIR pieces of tile t, the barrier publishes tile t to the consumers and tells the producers
+// that the consumers are done with the buffer the next DMA overwrites.
+constexpr int GROUP_NST = 4;       // 128 KiB ring: three tiles in flight
+constexpr int GROUP_THREADS = 512;
+
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void gemm_grouped_tn_kernel(GroupArgs g) {
+__global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArgs g) {
   constexpr int BK = TileGeom<T, false>::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int pi = 0;
@@ -466,12 +572,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_grouped_tn_kernel(GroupArgs g) 
   const int local = blockIdx.x - P.tile_start;
   const int m0 = (local / nbx) * BM, n0 = (local % nbx) * BN;
   const int nt = K / BK;
-  const int wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool consumer = wave < 4;
+  const int wm = ((wave & 3) >> 1) * 64, wn = (wave & 1) * 64;
 
-  Dma<T, false> da; Dma<T, false> db;
-  da.init(reinterpret_cast<const T*>(P.A), P.lda, P.a_bytes, m0, 0);
-  db.init(reinterpret_cast<const T*>(P.B), P.ldb, P.b_bytes, n0, 0);
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -481,30 +585,46 @@ __global__ __launch_bounds__(NTHREADS) void gemm_grouped_tn_kernel(GroupArgs g) 
   cs.clear();
   const bool do_colsum = P.a_colsum && n0 == 0;
 
-  if (nt > 0) { da.issue(smem, 0); db.issue(smem + TILE_BYTES, 0); }
-  if (nt > 1) { da.issue(smem + STAGE_BYTES, 1); db.issue(smem + STAGE_BYTES + TILE_BYTES, 1); }
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    if (t + 2 < nt) {
-      const int nxt = (cur + 2 >= NST) ? cur + 2 - NST : cur + 2;
-      da.issue(smem + nxt * STAGE_BYTES, t + 2);
-      db.issue(smem + nxt * STAGE_BYTES + TILE_BYTES, t + 2);
+  if (!consumer) {
+    // ------------------------------------------------------------ producer waves
+    Dma<T, false> da; Dma<T, false> db;
+    da.init(reinterpret_cast<const T*>(P.A), P.lda, P.a_bytes, m0, 0, wave - 4);
+    db.init(reinterpret_cast<const T*>(P.B), P.ldb, P.b_bytes, n0, 0, wave - 4);
+#pragma unroll
+    for (int s0 = 0; s0 < GROUP_NST - 1; ++s0)
+      if (s0 < nt) { da.issue(smem + s0 * STAGE_BYTES, s0); db.issue(smem + s0 * STAGE_BYTES + TILE_BYTES, s0); }
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int newer = min(GROUP_NST - 2, nt - 1 - t);
+      if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      if (t + GROUP_NST - 1 < nt) {
+        const int nxt = (cur == 0) ? GROUP_NST - 1 : cur - 1;
+        da.issue(smem + nxt * STAGE_BYTES, t + GROUP_NST - 1);
+        db.issue(smem + nxt * STAGE_BYTES + TILE_BYTES, t + GROUP_NST - 1);
+      }
+      cur = (cur + 1 == GROUP_NST) ? 0 : cur + 1;
     }
-    const char* ta = smem + cur * STAGE_BYTES;
-    compute_tile<T, IMT_TN>(acc, ta, ta + TILE_BYTES, wm, wn);
-    if (do_colsum) cs.add_tile(ta);
-    cur = (cur + 1 == NST) ? 0 : cur + 1;
+  } else {
+    // ------------------------------------------------------------ consumer waves
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_barrier" ::: "memory");
+      const char* ta = smem + cur * STAGE_BYTES;
+      compute_tile<T, IMT_TN>(acc, ta, ta + TILE_BYTES, wm, wn);
+      if (do_colsum) cs.add_tile(ta);
+      cur = (cur + 1 == GROUP_NST) ? 0 : cur + 1;
+    }
   }
   EpiParams ep;
   ep.C = P.C; ep.ldc = P.ldc; ep.c_f32 = 1; ep.accumulate = 1;
   ep.bias = nullptr; ep.resid = nullptr; ep.ldr = 0; ep.aux = nullptr; ep.ldaux = 0; ep.aux_mode = IMT_AUX_NONE;
   ep.atomic = 0; ep.alpha = g.alpha; ep.alpha_dev = nullptr; ep.inv_keep = 1.f; ep.drop_thresh = 0; ep.seed = 0;
   ep.a_colsum = P.a_colsum; ep.dbg = 0;
-  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
-  if (do_colsum) cs.flush(smem, P.a_colsum, m0, M, g.alpha);
+  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha, consumer);
+  if (do_colsum) cs.flush(smem, P.a_colsum, m0, M, g.alpha, consumer);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -532,7 +652,15 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
                     ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * esc, st);
   const T* A = reinterpret_cast<const T*>(a->A);
   const T* B = reinterpret_cast<const T*>(a->B);
-  if (variant == 3) {
+  if (variant == 5) {
+    static bool ws_attr = false;
+    auto kws = gemm_ws_kernel<T, LAYOUT>;
+    if (!ws_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kws), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS); ws_attr = true; }
+    const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
+    const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
+    const int tiles = nbx * nby;
+    hipLaunchKernelGGL(kws, dim3(tiles < 256 ? tiles : 256), dim3(WS_THREADS), WS_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ep);
+  } else if (variant == 3) {
     hipLaunchKernelGGL((gemm_sb_kernel<T, LAYOUT>), grid, dim3(NTHREADS), STAGE_BYTES, st, A, a->lda, B, a->ldb, a->M, a->N, a->K, k_per_split, ep);
   } else if (variant == 2 || variant == 4) {
     const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
@@ -600,8 +728,16 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   const int dbg = a->force_general / 100;
   // measured on MI355X (profiles/r01_v3_gemm_shapes.txt): about one wave of blocks -> the LDS-DMA ring (its long
   // steady state wins when K >= 1024, a tie otherwise); larger grids -> three single-buffer blocks per CU.
-  if (variant == 0) variant = (a->layout == IMT_TN) ? 1 : 3;  // measured best after the LDS-staged epilogue (profiles/r01_v4_gemm_shapes.txt)
+  // measured on MI355X (profiles/r01_v5_gemm_shapes.txt): the persistent wave-specialised kernel wins whenever a CU
+  // gets about one output tile or K is long (740 vs 480 TFLOP/s at 8192x512x2048); grids of many short-K tiles are
+  // still better served by three single-buffer blocks per CU overlapping each other's epilogues.
+  if (variant == 0) {
+    const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
+    if (pipe_ok && splits == 1 && (tiles <= 256 || a->K >= 1024)) variant = 5;
+    else variant = (a->layout == IMT_TN) ? 1 : 3;
+  }
   if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;
+  if (variant == 5 && (!pipe_ok || splits > 1)) variant = 3;
   EpiParams ep;
   ep.C = a->C; ep.ldc = a->ldc; ep.c_f32 = c_f32; ep.accumulate = a->accumulate;
   ep.bias = a->bias; ep.resid = a->resid; ep.ldr = a->ldr;
@@ -662,15 +798,15 @@ extern "C" int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* s
   g.total_tiles = start;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_NST * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_NST * STAGE_BYTES);
     attr_set = true;
   }
   ImtProfScope prof(dtype == IMT_BF16 ? "gemm_bf16_tn_grouped" : "gemm_f32_tn_grouped", flops, bytes, st);
   if (dtype == IMT_F32)
-    hipLaunchKernelGGL(gemm_grouped_tn_kernel<float>, dim3(start), dim3(NTHREADS), NST * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL(gemm_grouped_tn_kernel<float>, dim3(start), dim3(GROUP_THREADS), GROUP_NST * STAGE_BYTES, st, g);
   else
-    hipLaunchKernelGGL(gemm_grouped_tn_kernel<bf16_t>, dim3(start), dim3(NTHREADS), NST * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL(gemm_grouped_tn_kernel<bf16_t>, dim3(start), dim3(GROUP_THREADS), GROUP_NST * STAGE_BYTES, st, g);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }

@@ -279,3 +279,52 @@ def test_save_load_roundtrip(cuda, tmp_path):
     a = ours(b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
     c = loaded.eval()(b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
     assert torch.equal(a, c)
+
+
+def test_training_mode_dropout_is_consistent_between_forward_and_backward(cuda):
+    """Dropout masks are regenerated in backward from (seed, element index).  With the seed pinned the train-mode loss
+    is a deterministic function of the parameters, so analytic gradients must match central finite differences --
+    this fails if ANY of the ~10 dropout sites per layer (embedding, attention probabilities, dense outputs) uses a
+    different mask in backward than in forward."""
+    ref, ours = _pair(enc=1, dec=1, d=64, ff=128, heads=2)
+    ours.train()
+    for st in ours._stacks():
+        st._imt_dropout_seed = 12345
+    b = _toy_batch(B=4, S=16, T=16)
+    args = (b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
+
+    def loss_value():
+        with torch.no_grad():
+            return float(ours.loss_fused(*args)[0])
+
+    l1, l2 = loss_value(), loss_value()
+    assert l1 == l2, "train-mode forward is not deterministic for a pinned seed"
+    ours.eval()
+    l_eval = loss_value()
+    ours.train()
+    assert abs(l1 - l_eval) > 1e-6, "dropout had no effect in training mode"
+    ours.zero_grad()
+    loss, _ = ours.loss_fused(*args)
+    loss.backward()
+    named = dict(ours.named_parameters())
+    checks = [("encoder.encoder.layer.0.attention.self.value.weight", (3, 5)),
+              ("encoder.encoder.layer.0.intermediate.dense.weight", (7, 11)),
+              ("decoder.decoder.layer.0.crossattention.self.query.weight", (2, 9)),
+              ("decoder.decoder.layer.0.output.dense.bias", (13,)),
+              ("encoder.embeddings.LayerNorm.weight", (6,)),
+              ("output_layer.1.layer.bias", (int(b["dst_texts"][0, 1]),))]
+    eps = 2e-2
+    for key, idx in checks:
+        p = named[key]
+        g = float(p.grad[idx])
+        with torch.no_grad():
+            old = float(p[idx])
+            p[idx] = old + eps
+        lp = loss_value()
+        with torch.no_grad():
+            p[idx] = old - eps
+        lm = loss_value()
+        with torch.no_grad():
+            p[idx] = old
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - g) <= 0.08 * max(abs(fd), abs(g)) + 2e-5, "%s%s: analytic %.6g vs finite-difference %.6g" % (key, idx, g, fd)

@@ -151,7 +151,7 @@ def test_gemm_pipelined_vs_general_kernel(cuda, dtype, layout):
         da = wa.to(dtype).to(cuda)[:, 8:8 + a_in.shape[1]]
         db = wb.to(dtype).to(cuda)[:, 16:16 + b_in.shape[1]]
         outs = []
-        for force in (2, 1, 3):  # LDS-DMA pipeline, register-staged double buffer, single-buffer high-occupancy
+        for force in (2, 1, 3, 5):  # LDS-DMA ring, register double buffer, single buffer, persistent wave-specialised
             out = torch.zeros((M, N), device=cuda, dtype=torch.float32)
             O.gemm(da, db, layout, out=out, split_k=sk if layout == O.IMT_TN else 1,
                    accumulate=False, force_general=force)
@@ -160,6 +160,7 @@ def test_gemm_pipelined_vs_general_kernel(cuda, dtype, layout):
             layout, (M, N, K), float((outs[0] - ref).abs().max()))
         assert torch.equal(outs[1], ref), "general kernel wrong"
         assert torch.equal(outs[2], ref), "single-buffer kernel wrong"
+        assert torch.equal(outs[3], ref), "wave-specialised kernel wrong"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -42,11 +42,11 @@ def main():
     ]
     for lay, M, N, K, name in shapes:
         res = []
-        for variant in (1, 2, 3, 4):
-            if variant in (2, 4) and K % 64:
+        for variant in (1, 2, 3, 5):
+            if variant in (2, 5) and K % 64:
                 res.append((0.0, 0.0)); continue
             res.append(bench(lay, M, N, K, force_general=variant))
-        print("%-14s %s M=%5d N=%5d K=%5d  dbuf %6.1f us %5.0f TF | dma3 %6.1f us %5.0f TF | sbuf %6.1f us %5.0f TF | dma4 %6.1f us %5.0f TF" % (
+        print("%-14s %s M=%5d N=%5d K=%5d  dbuf %6.1f us %5.0f TF | dma3 %6.1f us %5.0f TF | sbuf %6.1f us %5.0f TF | ws %6.1f us %5.0f TF" % (
             name, names[lay], M, N, K, res[0][0], res[0][1], res[1][0], res[1][1], res[2][0], res[2][1], res[3][0], res[3][1]), flush=True)
     for (M, N, name) in [(3 * d, d, "qkv dW"), (d, d, "attn-out dW"), (ff, d, "ffn1 dW"), (d, ff, "ffn2 dW")]:
         for sk in (1, 4):
