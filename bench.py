@@ -200,13 +200,21 @@ def main():
         flops = algorithmic_flops(c)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         # dominant kernel = the kernel kind with the largest summed device time in the instrumented pass
-        gemm_rows = [r for r in rows if r["kind"].startswith("gemm_")]
+        gemm_rows = [r for r in rows if r["kind"].startswith("gemm_") and " " not in r["kind"]]
         dom = max(gemm_rows, key=lambda r: r["ms"]) if gemm_rows else None
         roofline = None
         if dom is not None:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            traffic = None
+            try:  # HBM bytes per launch of this kernel kind from the committed PMC passes (tools/collect_traffic.sh)
+                pt = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if args.config == "c1" and world == 1:
+                    traffic = round(pt["per_kind"][dom["kind"]]["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
             roofline = {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None,
+                        "frac": round(ach / peak, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": round(dom["bytes"] / max(1, dom["launches"])),
                         "launches_per_step": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / max(1, dom["launches"]), 2),
                         "step_frac": round(flops / (ms_per_step * 1e-3) / 1e12 / peak, 4),
                         "step_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2)}

@@ -88,9 +88,10 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * RB];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * RB];
-  __shared__ uint8_t kmask_s[64];
+  constexpr int NSUB = (RB > 128) ? 1 : 2;  // 64-row sub-tiles staged per barrier pair (LDS budget)
+  __shared__ __attribute__((aligned(16))) char Ks[NSUB][64 * RB];
+  __shared__ __attribute__((aligned(16))) char Vs[NSUB][64 * RB];
+  __shared__ uint8_t kmask_s[NSUB * 64];
 
   const int nqt = (p.Tq + 63) / 64;
   const int lid = imt_xcd_block(blockIdx.x, gridDim.x);  // batch-major: XCD x owns batches [x*B/8, (x+1)*B/8)
@@ -112,15 +113,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int nkt = (p.Tk + 63) / 64;
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-    stage_tile<T, DH>(Ks, Kb, p.ldk, kt * 64, p.Tk);
-    stage_tile<T, DH>(Vs, Vb, p.ldv, kt * 64, p.Tk);
-    if (threadIdx.x < 64) {
-      const int j = kt * 64 + threadIdx.x;
+  for (int kt0 = 0; kt0 < nkt; kt0 += NSUB) {
+    __syncthreads();  // previous tiles fully consumed
+    // all the loads of up to NSUB key tiles (K, V, mask) are in flight together: one memory round trip per 128 keys
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (kt0 + sub < nkt) {
+        stage_tile<T, DH>(Ks[sub], Kb, p.ldk, (kt0 + sub) * 64, p.Tk);
+        stage_tile<T, DH>(Vs[sub], Vb, p.ldv, (kt0 + sub) * 64, p.Tk);
+      }
+    }
+    if (threadIdx.x < NSUB * 64) {
+      const int j = kt0 * 64 + threadIdx.x;
       kmask_s[threadIdx.x] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
     }
     __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+    const int kt = kt0 + sub;
+    if (kt >= nkt) break;
+    const char* Kt = Ks[sub];
+    const char* Vt = Vs[sub];
+    const uint8_t* kmask_t = kmask_s + 64 * sub;
 
     // S^T tiles: rows <- keys (16 per tile), cols <- this wave's 16 queries
     f32x4 s[4];
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     for (int nt = 0; nt < 4; ++nt) {
       s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < NS; ++ks) mma16(s[nt], lds_frag_kcontig<T, RB>(Ks, 16 * nt, 4 * ks), qf[ks]);
+      for (int ks = 0; ks < NS; ++ks) mma16(s[nt], lds_frag_kcontig<T, RB>(Kt, 16 * nt, 4 * ks), qf[ks]);
     }
     float tmax = -INFINITY;
 #pragma unroll
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int jl = 16 * nt + 4 * g + e, j = kt * 64 + jl;
-        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_s[jl] != 0, query_ok) ? 0.f : -10000.0f);
+        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
         if (j >= p.Tk) v = -INFINITY;
         s[nt][e] = v;
         tmax = fmaxf(tmax, v);
@@ -168,8 +182,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     for (int u = 0; u < AccOperand<T>::NFR; ++u) {
       const frag_t pf = AccOperand<T>::get(s, u);
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) mma16(o[dt], AccOperand<T>::template lds<RB>(Vs, u, 16 * dt), pf);
+      for (int dt = 0; dt < NDT; ++dt) mma16(o[dt], AccOperand<T>::template lds<RB>(Vt, u, 16 * dt), pf);
     }
+    }  // sub
   }
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -212,9 +227,10 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * RB];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * RB];
-  __shared__ uint8_t kmask_s[64];
+  constexpr int NSUB = (RB > 128) ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) char Ks[NSUB][64 * RB];
+  __shared__ __attribute__((aligned(16))) char Vs[NSUB][64 * RB];
+  __shared__ uint8_t kmask_s[NSUB * 64];
 
   const int nqt = (p.Tq + 63) / 64;
   const int lid = imt_xcd_block(blockIdx.x, gridDim.x);  // batch-major: XCD x owns batches [x*B/8, (x+1)*B/8)
@@ -254,15 +270,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (p.Tk + 63) / 64;
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt0 = 0; kt0 < nkt; kt0 += NSUB) {
     __syncthreads();
-    stage_tile<T, DH>(Ks, Kb, p.ldk, kt * 64, p.Tk);
-    stage_tile<T, DH>(Vs, Vb, p.ldv, kt * 64, p.Tk);
-    if (threadIdx.x < 64) {
-      const int j = kt * 64 + threadIdx.x;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (kt0 + sub < nkt) {
+        stage_tile<T, DH>(Ks[sub], Kb, p.ldk, (kt0 + sub) * 64, p.Tk);
+        stage_tile<T, DH>(Vs[sub], Vb, p.ldv, (kt0 + sub) * 64, p.Tk);
+      }
+    }
+    if (threadIdx.x < NSUB * 64) {
+      const int j = kt0 * 64 + threadIdx.x;
       kmask_s[threadIdx.x] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
     }
     __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+    const int kt = kt0 + sub;
+    if (kt >= nkt) break;
+    const char* Kt = Ks[sub];
+    const char* Vt = Vs[sub];
+    const uint8_t* kmask_t = kmask_s + 64 * sub;
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -270,8 +298,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
       dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
-        mma16(s[nt], lds_frag_kcontig<T, RB>(Ks, 16 * nt, 4 * ks), qf[ks]);
-        mma16(dp[nt], lds_frag_kcontig<T, RB>(Vs, 16 * nt, 4 * ks), dof[ks]);
+        mma16(s[nt], lds_frag_kcontig<T, RB>(Kt, 16 * nt, 4 * ks), qf[ks]);
+        mma16(dp[nt], lds_frag_kcontig<T, RB>(Vt, 16 * nt, 4 * ks), dof[ks]);
       }
     }
 #pragma unroll
@@ -279,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int jl = 16 * nt + 4 * g + e, j = kt * 64 + jl;
-        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_s[jl] != 0, query_ok) ? 0.f : -10000.0f);
+        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
         float pv = (j < p.Tk) ? __expf(v - lse_i) : 0.f;
         float dpv = dp[nt][e];
         if (p.drop_thresh) {
@@ -292,8 +320,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     for (int u = 0; u < AccOperand<T>::NFR; ++u) {
       const frag_t dsf = AccOperand<T>::get(s, u);
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) mma16(dq[dt], AccOperand<T>::template lds<RB>(Ks, u, 16 * dt), dsf);
+      for (int dt = 0; dt < NDT; ++dt) mma16(dq[dt], AccOperand<T>::template lds<RB>(Kt, u, 16 * dt), dsf);
     }
+    }  // sub
   }
   if (i < p.Tq) {
     T* dQb = reinterpret_cast<T*>(p.dQ) + ((int64_t)b * p.Tq + i) * p.lddq + h * DH;
@@ -307,10 +336,11 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
-  __shared__ __attribute__((aligned(16))) char Qs[64 * RB];
-  __shared__ __attribute__((aligned(16))) char dOs[64 * RB];
-  __shared__ float lse_s[64], delta_s[64];
-  __shared__ uint8_t qmask_s[64];
+  constexpr int NSUB = (RB > 128) ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) char Qs[NSUB][64 * RB];
+  __shared__ __attribute__((aligned(16))) char dOs[NSUB][64 * RB];
+  __shared__ float lse_s[NSUB * 64], delta_s[NSUB * 64];
+  __shared__ uint8_t qmask_s[NSUB * 64];
 
   const int nkt0 = (p.Tk + 63) / 64;
   const int lid = imt_xcd_block(blockIdx.x, gridDim.x);
@@ -333,18 +363,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
   for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqt = (p.Tq + 63) / 64;
-  for (int qt = 0; qt < nqt; ++qt) {
+  for (int qt0 = 0; qt0 < nqt; qt0 += NSUB) {
     __syncthreads();
-    stage_tile<T, DH>(Qs, Qb, p.ldq, qt * 64, p.Tq);
-    stage_tile<T, DH>(dOs, dOb, p.lddo, qt * 64, p.Tq);
-    if (threadIdx.x < 64) {
-      const int i = qt * 64 + threadIdx.x;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (qt0 + sub < nqt) {
+        stage_tile<T, DH>(Qs[sub], Qb, p.ldq, (qt0 + sub) * 64, p.Tq);
+        stage_tile<T, DH>(dOs[sub], dOb, p.lddo, (qt0 + sub) * 64, p.Tq);
+      }
+    }
+    if (threadIdx.x < NSUB * 64) {
+      const int i = qt0 * 64 + threadIdx.x;
       const int64_t srow = ((int64_t)b * p.H + h) * p.Tq + (i < p.Tq ? i : 0);
       lse_s[threadIdx.x] = p.lse[srow];
       delta_s[threadIdx.x] = p.delta[srow];
       qmask_s[threadIdx.x] = (i < p.Tq) ? (p.query_mask ? p.query_mask[(int64_t)b * p.Tq + i] : (uint8_t)1) : (uint8_t)1;
     }
     __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+    const int qt = qt0 + sub;
+    if (qt >= nqt) break;
+    const char* Qt = Qs[sub];
+    const char* dOt = dOs[sub];
+    const float* lse_t = lse_s + 64 * sub;
+    const float* delta_t = delta_s + 64 * sub;
+    const uint8_t* qmask_t = qmask_s + 64 * sub;
     // S tiles: rows <- queries (16 per tile), cols <- this wave's 16 keys
     f32x4 s[4], dp[4];
 #pragma unroll
@@ -353,8 +397,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
       dp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NS; ++ks) {
-        mma16(s[mt], lds_frag_kcontig<T, RB>(Qs, 16 * mt, 4 * ks), kf[ks]);
-        mma16(dp[mt], lds_frag_kcontig<T, RB>(dOs, 16 * mt, 4 * ks), vf[ks]);
+        mma16(s[mt], lds_frag_kcontig<T, RB>(Qt, 16 * mt, 4 * ks), kf[ks]);
+        mma16(dp[mt], lds_frag_kcontig<T, RB>(dOt, 16 * mt, 4 * ks), vf[ks]);
       }
     }
     f32x4 pd[4];  // dropped P (operand of dV)
@@ -363,8 +407,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int il = 16 * mt + 4 * g + e, i = qt * 64 + il;
-        float v = s[mt][e] * p.scale + (mask_ok(p, b, i, j, key_ok, qmask_s[il] != 0) ? 0.f : -10000.0f);
-        float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_s[il]) : 0.f;
+        float v = s[mt][e] * p.scale + (mask_ok(p, b, i, j, key_ok, qmask_t[il] != 0) ? 0.f : -10000.0f);
+        float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_t[il]) : 0.f;
         float dpv = dp[mt][e], pdv = pv;
         if (p.drop_thresh) {
           const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
@@ -373,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
           pdv = keep ? pv * p.inv_keep : 0.f;
         }
         pd[mt][e] = pdv;
-        s[mt][e] = pv * (dpv - delta_s[il]);  // dS
+        s[mt][e] = pv * (dpv - delta_t[il]);  // dS
       }
 #pragma unroll
     for (int u = 0; u < AccOperand<T>::NFR; ++u) {
@@ -381,10 +425,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
       const frag_t dsf = AccOperand<T>::get(s, u);
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        mma16(dv[dt], AccOperand<T>::template lds<RB>(dOs, u, 16 * dt), pf);   // dV^T[d][n] += dO^T[d][m] P[m][n]
-        mma16(dk[dt], AccOperand<T>::template lds<RB>(Qs, u, 16 * dt), dsf);   // dK^T[d][n] += Q^T[d][m] dS[m][n]
+        mma16(dv[dt], AccOperand<T>::template lds<RB>(dOt, u, 16 * dt), pf);   // dV^T[d][n] += dO^T[d][m] P[m][n]
+        mma16(dk[dt], AccOperand<T>::template lds<RB>(Qt, u, 16 * dt), dsf);   // dK^T[d][n] += Q^T[d][m] dS[m][n]
       }
     }
+    }  // sub
   }
   if (j < p.Tk) {
     T* dKb = reinterpret_cast<T*>(p.dK) + ((int64_t)b * p.Tk + j) * p.lddk + h * DH;

@@ -644,9 +644,17 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kpipe4), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
     attr_set = true;
   }
-  static const char* const kinds[2][3] = {{"gemm_f32_nt", "gemm_f32_nn", "gemm_f32_tn"}, {"gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn"}};
+  // profiler kind == one kernel symbol: gemm_<variant>_<dtype>_<layout> (variant: dbuf = gemm_kernel, dma = gemm_pipe_kernel,
+  // sbuf = gemm_sb_kernel, ws = gemm_ws_kernel) so that rocprofv3's per-symbol averages can be compared one to one
+  static const char* const kinds[6][2][3] = {
+      {{"", "", ""}, {"", "", ""}},
+      {{"gemm_dbuf_f32_nt", "gemm_dbuf_f32_nn", "gemm_dbuf_f32_tn"}, {"gemm_dbuf_bf16_nt", "gemm_dbuf_bf16_nn", "gemm_dbuf_bf16_tn"}},
+      {{"gemm_dma_f32_nt", "gemm_dma_f32_nn", "gemm_dma_f32_tn"}, {"gemm_dma_bf16_nt", "gemm_dma_bf16_nn", "gemm_dma_bf16_tn"}},
+      {{"gemm_sbuf_f32_nt", "gemm_sbuf_f32_nn", "gemm_sbuf_f32_tn"}, {"gemm_sbuf_bf16_nt", "gemm_sbuf_bf16_nn", "gemm_sbuf_bf16_tn"}},
+      {{"gemm_dma_f32_nt", "gemm_dma_f32_nn", "gemm_dma_f32_tn"}, {"gemm_dma_bf16_nt", "gemm_dma_bf16_nn", "gemm_dma_bf16_tn"}},
+      {{"gemm_ws_f32_nt", "gemm_ws_f32_nn", "gemm_ws_f32_tn"}, {"gemm_ws_bf16_nt", "gemm_ws_bf16_nn", "gemm_ws_bf16_tn"}}};
   const double es = sizeof(T), esc = ep.c_f32 ? 4.0 : es;
-  const char* kind = kinds[sizeof(T) == 2][LAYOUT];
+  const char* kind = kinds[variant >= 1 && variant <= 5 ? variant : 1][sizeof(T) == 2][LAYOUT];
   if (imt_prof_enabled() && getenv("IMT_PROF_SHAPES")) kind = imt_prof_intern(kind, a->M, a->N, a->K);
   ImtProfScope prof(kind, 2.0 * a->M * a->N * a->K,
                     ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * esc, st);

@@ -82,61 +82,67 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int row_begin = (imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + w) * rows_per_wave;
-  // software prefetch: the loads of row r+1 are issued before row r is reduced (each wave keeps two rows in flight)
-  f32x4 nx[NCH], nd[NCH];
-  auto preload = [&](int row) {
+  // rows are processed in batches of RB: all loads of a batch are issued before the first reduction, so a wave keeps
+  // 2*RB row loads in flight (with ~1 wave per SIMD the row loop is otherwise a chain of exposed memory latencies)
+  constexpr int RB = 4;
+  for (int r0 = 0; r0 < rows_per_wave; r0 += RB) {
+    f32x4 xb[RB][NCH], db[RB][NCH];
+    float mub[RB], rsb[RB];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane * 4 + i * 256;
-      nx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      nd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < d && row < rows) {
-        nx[i] = Vec4<T>::load(x + (int64_t)row * d + c);
-        nd[i] = Vec4<T>::load(dy + (int64_t)row * d + c);
-      }
-    }
-  };
-  preload(row_begin);
-  for (int rr = 0; rr < rows_per_wave; ++rr) {
-    const int row = row_begin + rr;
-    if (row >= rows) break;
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NCH], dyv[NCH];
+    for (int k = 0; k < RB; ++k) {
+      const int row = row_begin + r0 + k;
+      const bool live = (r0 + k < rows_per_wave) && (row < rows);
+      mub[k] = live ? mean[row] : 0.f;
+      rsb[k] = live ? rstd[row] : 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) { xh[i] = nx[i]; dyv[i] = nd[i]; }
-    if (rr + 1 < rows_per_wave) preload(row + 1);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane * 4 + i * 256;
-      if (c < d) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (y_thresh) dyv[i][e] = dropout_keep(y_seed, (uint64_t)row * d + c + e, y_thresh) ? dyv[i][e] * y_inv_keep : 0.f;
-          xh[i][e] = (xh[i][e] - mu) * rs;
-          const float dg = dyv[i][e] * g[i][e];
-          s1 += dg;
-          s2 += dg * xh[i][e];
-          ag[i][e] += dyv[i][e] * xh[i][e];
-          ab[i][e] += dyv[i][e];
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane * 4 + i * 256;
+        xb[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live && c < d) {
+          xb[k][i] = Vec4<T>::load(x + (int64_t)row * d + c);
+          db[k][i] = Vec4<T>::load(dy + (int64_t)row * d + c);
         }
       }
     }
-    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane * 4 + i * 256;
-      if (c < d) {
-        f32x4 o;
+    for (int k = 0; k < RB; ++k) {
+      const int row = row_begin + r0 + k;
+      if (!((r0 + k < rows_per_wave) && (row < rows))) continue;  // wave-uniform
+      const float mu = mub[k], rs = rsb[k];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[i][e] * g[i][e] - c1 - xh[i][e] * c2);
-        Vec4<T>::store(dx + (int64_t)row * d + c, o);
-        if (dx_drop) {
-          f32x4 o2;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < d) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o2[e] = (!dx_thresh || dropout_keep(dx_seed, (uint64_t)row * d + c + e, dx_thresh)) ? o[e] * dx_inv_keep : 0.f;
-          Vec4<T>::store(dx_drop + (int64_t)row * d + c, o2);
+          for (int e = 0; e < 4; ++e) {
+            if (y_thresh) db[k][i][e] = dropout_keep(y_seed, (uint64_t)row * d + c + e, y_thresh) ? db[k][i][e] * y_inv_keep : 0.f;
+            xb[k][i][e] = (xb[k][i][e] - mu) * rs;
+            const float dg = db[k][i][e] * g[i][e];
+            s1 += dg;
+            s2 += dg * xb[k][i][e];
+            ag[i][e] += db[k][i][e] * xb[k][i][e];
+            ab[i][e] += db[k][i][e];
+          }
+        }
+      }
+      const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < d) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rs * (db[k][i][e] * g[i][e] - c1 - xb[k][i][e] * c2);
+          Vec4<T>::store(dx + (int64_t)row * d + c, o);
+          if (dx_drop) {
+            f32x4 o2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o2[e] = (!dx_thresh || dropout_keep(dx_seed, (uint64_t)row * d + c + e, dx_thresh)) ? o[e] * dx_inv_keep : 0.f;
+            Vec4<T>::store(dx_drop + (int64_t)row * d + c, o2);
+          }
         }
       }
     }

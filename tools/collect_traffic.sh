@@ -1,0 +1,29 @@
+#!/bin/bash
+# HBM traffic of the GEMM kernels inside the bench step, by PMC counters (separate passes, counters only), corrected as
+# MI355X_MICROARCH.md "HBM" prescribes: bytes = 2 * FETCH_SIZE*1024 (gfx950 reports half of a wide coalesced read
+# stream) + WRITE_SIZE*1024.  Writes profiles/r01_pmc_traffic.json (per-launch averages per kernel symbol).
+set -e
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+python3 - <<PY
+import csv, glob, json, collections, re
+def load(kind):
+    agg = collections.defaultdict(list)
+    for f in glob.glob("$OUT/%s/*/*counter_collection.csv" % kind):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+fe, wr = load("fetch"), load("write")
+out = {}
+for k in fe:
+    short = re.sub(r"\(anonymous namespace\)::", "", k)[:120]
+    n = len(fe[k]); w = wr.get(k, [0.0])
+    out[short] = {"launches": n, "fetch_kb_avg": sum(fe[k]) / n, "write_kb_avg": sum(w) / max(1, len(w)),
+                  "hbm_bytes_avg": (2.0 * sum(fe[k]) / n + sum(w) / max(1, len(w))) * 1024.0}
+json.dump(out, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_avg"] * kv[1]["launches"])[:14]:
+    print("%-100s n=%4d  %8.1f MB/launch" % (k[:100], v["launches"], v["hbm_bytes_avg"] / 1e6))
+PY
