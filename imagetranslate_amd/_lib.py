@@ -100,6 +100,42 @@ class StackIO(Structure):
     ]
 
 
+class AttnDecodeArgs(Structure):
+    _fields_ = [
+        ("dtype", c_int32),
+        ("R", c_int32), ("H", c_int32), ("head_dim", c_int32), ("n_keys", c_int32), ("rep", c_int32),
+        ("Q", c_void_p), ("ldq", c_int64),
+        ("K", c_void_p), ("V", c_void_p), ("ld_row", c_int64), ("ld_pos", c_int64),
+        ("slots", c_void_p), ("ld_slots", c_int64),
+        ("key_mask", c_void_p), ("ld_mask", c_int64),
+        ("O", c_void_p), ("ldo", c_int64),
+        ("scale", c_float), ("reserved", c_int32),
+    ]
+
+
+class DecodeIO(Structure):
+    _fields_ = [
+        ("R", c_int32), ("rep", c_int32), ("pos", c_int32), ("Tk", c_int32), ("t_max", c_int32), ("r_max", c_int32),
+        ("ids", c_void_p), ("type_ids", c_void_p), ("pos_ids", c_void_p), ("slots", c_void_p), ("enc_mask", c_void_p),
+        ("self_cache", c_void_p), ("cross_kv", c_void_p), ("out", c_void_p),
+    ]
+
+
+class BeamArgs(Structure):
+    _fields_ = [
+        ("B", c_int32), ("beam", c_int32), ("rep", c_int32), ("V", c_int32), ("step", c_int32), ("t_max", c_int32),
+        ("logits", c_void_p), ("ld", c_int64),
+        ("scores_in", c_void_p), ("sizes_in", c_void_p), ("eos_in", c_void_p), ("max_lens", c_void_p),
+        ("hist_in", c_void_p), ("slots_in", c_void_p),
+        ("len_penalty_ratio", c_float), ("reserved", c_int32),
+        ("pad_idx", c_int64), ("eos", c_int64),
+        ("cand_scores", c_void_p), ("cand_idx", c_void_p),
+        ("scores_out", c_void_p), ("sizes_out", c_void_p), ("eos_out", c_void_p),
+        ("hist_out", c_void_p), ("slots_out", c_void_p), ("parent_out", c_void_p), ("tokens_out", c_void_p),
+        ("eos_count", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/imt_hip.h declares (tests/test_cabi.py checks)
 _P = c_void_p
 SIGNATURES = {
@@ -132,6 +168,13 @@ SIGNATURES = {
     "imt_stack_workspace_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int, c_int]),
     "imt_stack_forward": (c_int, [POINTER(StackDesc), POINTER(StackIO), _P, c_int64, _P]),
     "imt_stack_backward": (c_int, [POINTER(StackDesc), POINTER(StackIO), _P, c_int64, c_int, c_int, _P]),
+    "imt_attention_decode": (c_int, [POINTER(AttnDecodeArgs), _P]),
+    "imt_decode_workspace_bytes": (c_int64, [POINTER(StackDesc), c_int]),
+    "imt_decode_self_cache_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int]),
+    "imt_decode_cross_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int]),
+    "imt_decode_begin": (c_int, [POINTER(StackDesc), _P, c_int, c_int, _P, _P]),
+    "imt_decode_step": (c_int, [POINTER(StackDesc), POINTER(DecodeIO), _P, c_int64, _P]),
+    "imt_beam_step": (c_int, [POINTER(BeamArgs), _P]),
 }
 
 _lib = None

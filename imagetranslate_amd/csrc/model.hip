@@ -356,3 +356,125 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   }
   return IMT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ incremental decoding
+namespace {
+
+struct DecodeWs {
+  void* emb_sum; void* x; void* ctx; void* pre_ln; void* a; void* q; void* b; void* h; void* z; float* mean; float* rstd;
+  int64_t bytes;
+};
+
+void carve_decode(const imt_stack_desc* m, int r_max, void* ws, DecodeWs& w) {
+  Carver c(ws);
+  const int64_t R = r_max, d = m->d, ff = m->ff, es = esize(m->dtype);
+  w.emb_sum = c.take(R * d * es); w.x = c.take(R * d * es); w.ctx = c.take(R * d * es); w.pre_ln = c.take(R * d * es);
+  w.a = c.take(R * d * es); w.q = c.take(R * d * es); w.b = c.take(R * d * es);
+  w.h = c.take(R * ff * es); w.z = c.take(R * ff * es);
+  w.mean = (float*)c.take(R * 4); w.rstd = (float*)c.take(R * 4);
+  w.bytes = c.off;
+}
+
+int validate_decoder(const imt_stack_desc* m) {
+  IMT_CHECK_ARG(m, "decode: null descriptor");
+  IMT_CHECK_ARG(m->dtype == IMT_F32 || m->dtype == IMT_BF16, "decode: bad dtype");
+  IMT_CHECK_ARG(m->is_decoder, "decode: stack is not a decoder");
+  IMT_CHECK_ARG(m->n_layers > 0 && m->n_layers <= MAX_LAYERS && m->layers, "decode: bad layer table");
+  IMT_CHECK_ARG(m->d > 0 && m->heads > 0 && m->d % m->heads == 0, "decode: hidden size %d not a multiple of heads %d", m->d, m->heads);
+  const int dh = m->d / m->heads;
+  IMT_CHECK_ARG(dh == 32 || dh == 64, "decode: head_dim %d unsupported (32 or 64)", dh);
+  IMT_CHECK_ARG(m->d % 8 == 0 && m->ff % 8 == 0, "decode: d and ff must be multiples of 8");
+  IMT_CHECK_ARG(m->params, "decode: null parameter buffer");
+  for (int l = 0; l < m->n_layers; ++l)
+    IMT_CHECK_ARG(m->layers[l].cross_attn.qkv_w >= 0, "decode: layer %d has no crossattention block", l);
+  return IMT_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t imt_decode_workspace_bytes(const imt_stack_desc* m, int r_max) {
+  if (!m || r_max <= 0) return -1;
+  DecodeWs w;
+  carve_decode(m, r_max, nullptr, w);
+  return w.bytes;
+}
+extern "C" int64_t imt_decode_self_cache_bytes(const imt_stack_desc* m, int r_max, int t_max) {
+  if (!m || r_max <= 0 || t_max <= 0) return -1;
+  return (int64_t)m->n_layers * r_max * t_max * 3 * m->d * esize(m->dtype);
+}
+extern "C" int64_t imt_decode_cross_bytes(const imt_stack_desc* m, int B, int Tk) {
+  if (!m || B <= 0 || Tk <= 0) return -1;
+  return (int64_t)m->n_layers * B * Tk * 2 * m->d * esize(m->dtype);
+}
+
+extern "C" int imt_decode_begin(const imt_stack_desc* m, const void* enc_states, int B, int Tk, void* cross_kv, void* stream) {
+  RC(validate_decoder(m));
+  IMT_CHECK_ARG(enc_states && cross_kv && B > 0 && Tk > 0, "decode_begin: bad arguments");
+  Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  const int d = m->d;
+  const int64_t per_layer = (int64_t)B * Tk * 2 * d;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const imt_attn_block& p = m->layers[l].cross_attn;
+    RC(linear_fwd(c, enc_states, d, B * Tk, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d, 2 * d, offp(cross_kv, l * per_layer, c.es), 2 * d,
+                  nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+  }
+  return IMT_OK;
+}
+
+extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io, void* ws, int64_t ws_bytes, void* stream) {
+  RC(validate_decoder(m));
+  IMT_CHECK_ARG(io, "decode_step: null io");
+  IMT_CHECK_ARG(io->R > 0 && io->rep > 0 && io->R % io->rep == 0 && io->R <= io->r_max, "decode_step: bad row counts (R=%d rep=%d r_max=%d)", io->R, io->rep, io->r_max);
+  IMT_CHECK_ARG(io->pos >= 0 && io->pos < io->t_max && io->Tk > 0, "decode_step: position %d outside the cache (t_max=%d)", io->pos, io->t_max);
+  IMT_CHECK_ARG(io->ids && io->pos_ids && io->self_cache && io->cross_kv && io->out, "decode_step: null tensor");
+  DecodeWs w;
+  carve_decode(m, io->r_max, ws, w);
+  IMT_CHECK_ARG(ws && ws_bytes >= w.bytes, "decode_step: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
+  IMT_CHECK_ARG(((uintptr_t)ws & 255) == 0, "decode_step: workspace must be 256-B aligned");
+  Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  const int R = io->R, d = m->d, ff = m->ff, H = m->heads, dh = d / H;
+  const int64_t row3 = (int64_t)io->t_max * 3 * d;                       // one cache row (all positions)
+  const int64_t self_layer = (int64_t)io->r_max * row3;
+  const int B = R / io->rep;
+  const int64_t cross_layer = (int64_t)B * io->Tk * 2 * d;
+  RC(imt_embed_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), w.emb_sum, R, 1, d,
+                   m->vocab, m->max_pos, m->n_types, c.st));
+  RC(imt_layernorm_fwd(c.dtype, w.emb_sum, c.P(m->emb_ln_g), c.P(m->emb_ln_b), w.x, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+  const void* x = w.x;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const imt_layer_desc& p = m->layers[l];
+    // self attention: q|k|v of the new position straight into the cache row of each hypothesis
+    void* cache_l = offp(io->self_cache, l * self_layer, c.es);
+    void* qkv_new = offp(cache_l, (int64_t)io->pos * 3 * d, c.es);
+    RC(linear_fwd(c, x, d, R, d, p.self_attn.qkv_w, p.self_attn.qkv_b, 3 * d, qkv_new, row3, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    imt_attn_decode_args a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = c.dtype; a.R = R; a.H = H; a.head_dim = dh; a.n_keys = io->pos + 1; a.rep = 1;
+    a.Q = qkv_new; a.ldq = row3;
+    a.K = offp(cache_l, d, c.es); a.V = offp(cache_l, 2 * d, c.es); a.ld_row = row3; a.ld_pos = 3 * d;
+    a.slots = io->slots; a.ld_slots = io->t_max;
+    a.O = w.ctx; a.ldo = d; a.scale = 1.0f / sqrtf((float)dh);
+    RC(imt_attention_decode(&a, c.st));
+    RC(linear_fwd(c, w.ctx, d, R, d, p.self_attn.o_w, p.self_attn.o_b, d, w.pre_ln, d, x, d, nullptr, IMT_AUX_NONE, 0.f, 0));
+    RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.self_attn.ln_g), c.P(p.self_attn.ln_b), w.a, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+    // cross attention against the per-sentence K|V
+    RC(linear_fwd(c, w.a, d, R, d, p.cross_attn.qkv_w, p.cross_attn.qkv_b, d, w.q, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    const void* kv_l = offp(io->cross_kv, l * cross_layer, c.es);
+    memset(&a, 0, sizeof(a));
+    a.dtype = c.dtype; a.R = R; a.H = H; a.head_dim = dh; a.n_keys = io->Tk; a.rep = io->rep;
+    a.Q = w.q; a.ldq = d;
+    a.K = kv_l; a.V = offp(kv_l, d, c.es); a.ld_row = (int64_t)io->Tk * 2 * d; a.ld_pos = 2 * d;
+    a.key_mask = io->enc_mask; a.ld_mask = io->Tk;
+    a.O = w.ctx; a.ldo = d; a.scale = 1.0f / sqrtf((float)dh);
+    RC(imt_attention_decode(&a, c.st));
+    RC(linear_fwd(c, w.ctx, d, R, d, p.cross_attn.o_w, p.cross_attn.o_b, d, w.pre_ln, d, w.a, d, nullptr, IMT_AUX_NONE, 0.f, 0));
+    RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.cross_attn.ln_g), c.P(p.cross_attn.ln_b), w.b, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+    // feed-forward
+    RC(linear_fwd(c, w.b, d, R, d, p.ff1_w, p.ff1_b, ff, w.h, ff, nullptr, 0, w.z, IMT_AUX_GELU_FWD, 0.f, 0));
+    RC(linear_fwd(c, w.h, ff, R, ff, p.ff2_w, p.ff2_b, d, w.pre_ln, d, w.b, d, nullptr, IMT_AUX_NONE, 0.f, 0));
+    void* y = (l == m->n_layers - 1) ? io->out : w.x;
+    RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.ln2_g), c.P(p.ln2_b), y, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+    x = y;
+  }
+  return IMT_OK;
+}

@@ -265,3 +265,32 @@ def gated_mix(a, b, gate):
     out = torch.empty_like(a)
     L.check(L.load().imt_gated_mix(dt(a), _p(a), _p(b), _p(gate), _p(out), a.shape[0], a.shape[1], _stream()), "imt_gated_mix")
     return out
+
+
+# ------------------------------------------------------------------------------------------- incremental decoding
+def attention_decode(q, k_base, v_base, n_keys, heads, *, ld_row, ld_pos, rep=1, slots=None, key_mask=None, ldq=None,
+                     rows=None, scale=None):
+    """Single-query attention against a (slot-addressed) K/V cache; see include/imt_hip.h:imt_attention_decode.
+    ``k_base`` / ``v_base`` are tensors whose data_ptr is the (row 0, position 0, head 0) element."""
+    _req_cuda(q, k_base, v_base, slots, key_mask)
+    R = rows if rows is not None else q.shape[0]
+    d = q.shape[-1]
+    a = L.AttnDecodeArgs()
+    a.dtype, a.R, a.H, a.head_dim, a.n_keys, a.rep = dt(q), R, heads, d // heads, n_keys, rep
+    a.Q, a.ldq = q.data_ptr(), (ldq if ldq is not None else q.stride(0))
+    a.K, a.V, a.ld_row, a.ld_pos = k_base.data_ptr(), v_base.data_ptr(), ld_row, ld_pos
+    if slots is not None:
+        assert slots.dtype == torch.int32
+        a.slots, a.ld_slots = slots.data_ptr(), slots.stride(0)
+    if key_mask is not None:
+        assert key_mask.dtype == torch.uint8
+        a.key_mask, a.ld_mask = key_mask.data_ptr(), key_mask.stride(0)
+    out = torch.empty((R, d), device=q.device, dtype=q.dtype)
+    a.O, a.ldo = out.data_ptr(), d
+    a.scale = scale if scale is not None else 1.0 / math.sqrt(d // heads)
+    L.check(L.load().imt_attention_decode(ctypes.byref(a), _stream()), "imt_attention_decode")
+    return out
+
+
+def beam_step(args: "L.BeamArgs"):
+    L.check(L.load().imt_beam_step(ctypes.byref(args), _stream()), "imt_beam_step")

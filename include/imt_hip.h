@@ -278,6 +278,88 @@ int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io, void* ws,
 int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, int layer_lo,
                        int layer_hi, void* stream);
 
+/* ------------------------------------------------------------------ incremental decoding + beam search
+ * Replaces the per-step work of BeamDecoder.forward (src/seq_gen.py:131-227).  The reference re-runs the decoder
+ * on the whole prefix every step (:164-166) and re-projects the encoder states to cross K/V in every layer of
+ * every step; here each step processes ONE new position per hypothesis against
+ *   - a self-attention cache  [n_layers][r_max][t_max][3d]  (q|k|v of every position, written in place by the
+ *     fused QKV GEMM), addressed through a slot table so that beam re-ordering never copies the cache:
+ *     slots[r, j] = cache row that holds position j of hypothesis r (its ancestor at the time j was decoded);
+ *   - cross-attention K/V     [n_layers][B][Tk][2d]  projected once per sentence by imt_decode_begin and shared by
+ *     the `rep` hypotheses of a sentence (row r reads sentence r / rep).
+ * With the causal mask of BertDecoderModel (src/bert_seq2seq.py:69-71) the cached keys/values equal the
+ * recomputed ones, so the last-position hidden state is the reference's `decoder_states[:, -1, :]` (:191).
+ */
+typedef struct imt_attn_decode_args {
+  int32_t dtype;
+  int32_t R, H, head_dim; /* hypotheses, heads, 32|64 */
+  int32_t n_keys;         /* keys attended (self: pos+1; cross: Tk) */
+  int32_t rep;            /* hypotheses per sentence (mask row and, without slots, K/V row = r / rep) */
+  const void* Q; int64_t ldq;        /* query of hypothesis r at Q + r*ldq (+ h*head_dim) */
+  const void* K; const void* V;      /* element (row, j) at base + row*ld_row + j*ld_pos (+ h*head_dim) */
+  int64_t ld_row, ld_pos;
+  const int32_t* slots; int64_t ld_slots; /* [R, >= n_keys] or NULL (row = r / rep) */
+  const uint8_t* key_mask; int64_t ld_mask; /* [R/rep, n_keys]: (1-m)*-10000 added to the scaled score; nullable */
+  void* O; int64_t ldo;
+  float scale;
+  int32_t reserved;
+} imt_attn_decode_args;
+int imt_attention_decode(const imt_attn_decode_args* a, void* stream);
+
+typedef struct imt_decode_io {
+  int32_t R;               /* hypothesis rows this step (B at the first step, B*beam afterwards) */
+  int32_t rep;             /* rows per source sentence */
+  int32_t pos;             /* 0-based position being decoded == number of cached positions */
+  int32_t Tk;              /* encoder length */
+  int32_t t_max, r_max;    /* cache capacity: positions, rows */
+  const int64_t* ids;      /* [R] newest token of every hypothesis */
+  const int64_t* type_ids; /* [R] or NULL (zeros) */
+  const int64_t* pos_ids;  /* [R] position-embedding index (normally == pos) */
+  const int32_t* slots;    /* [R, t_max] slot table, slots[r, pos] == r ; NULL: every row reads its own cache row */
+  const uint8_t* enc_mask; /* [R/rep, Tk] encoder_attention_mask or NULL (ones) */
+  void* self_cache;        /* imt_decode_self_cache_bytes() */
+  const void* cross_kv;    /* imt_decode_cross_bytes(), filled by imt_decode_begin */
+  void* out;               /* [R, d] last-position hidden states (compute dtype) */
+} imt_decode_io;
+int64_t imt_decode_workspace_bytes(const imt_stack_desc* m, int r_max);
+int64_t imt_decode_self_cache_bytes(const imt_stack_desc* m, int r_max, int t_max);
+int64_t imt_decode_cross_bytes(const imt_stack_desc* m, int B, int Tk);
+/* cross K|V of every decoder layer from the encoder states [B,Tk,d] (one GEMM per layer). */
+int imt_decode_begin(const imt_stack_desc* m, const void* enc_states, int B, int Tk, void* cross_kv, void* stream);
+int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io, void* ws, int64_t ws_bytes, void* stream);
+
+/* One beam-search step on device (src/seq_gen.py:193-227): log-softmax of the [B*rep, V] logits, the EOS /
+ * length-limit zeroing (:194-196), length-penalised scores (:197-200, pow((len+6)/6, ratio)), top-`beam` over the
+ * rep*V continuations of each sentence with ties broken by the LOWEST flat index (torch.topk leaves it unspecified),
+ * the reference's PAD overwrites (:205-212, including that finished/over-limit slots take beam 0 as parent because
+ * the overwritten flat index is divided by V, :216 with floor division), and the bookkeeping (:214-227): token
+ * history, hypothesis sizes, scores, EOS flags, and the slot table of the self-attention cache.
+ * Row r of the inputs is hypothesis (r / rep, r % rep); outputs have B*beam rows.  `step` is the reference's loop
+ * index i (>= 1): inputs hold i tokens, outputs i+1.  eos_count[step] += number of output hypotheses containing EOS.
+ */
+typedef struct imt_beam_args {
+  int32_t B, beam, rep, V;
+  int32_t step, t_max;
+  const float* logits; int64_t ld; /* [B*rep, V] fp32 */
+  const float* scores_in;          /* [B*rep] */
+  const float* sizes_in;           /* [B*rep] (ignored when beam == 1) */
+  const uint8_t* eos_in;           /* [B*rep] hypothesis already contains EOS */
+  const int64_t* max_lens;         /* [B] */
+  const int64_t* hist_in;          /* [B*rep, t_max] */
+  const int32_t* slots_in;         /* [B*rep, t_max] or NULL */
+  float len_penalty_ratio;
+  int32_t reserved;
+  int64_t pad_idx, eos;
+  float* cand_scores; int32_t* cand_idx; /* workspace [B*rep, beam] each */
+  float* scores_out; float* sizes_out; uint8_t* eos_out; /* [B*beam] */
+  int64_t* hist_out;               /* [B*beam, t_max] */
+  int32_t* slots_out;              /* [B*beam, t_max] or NULL */
+  int32_t* parent_out;             /* [B*beam] input row each output hypothesis extends */
+  int64_t* tokens_out;             /* [B*beam] appended token */
+  int32_t* eos_count;              /* [t_max] (pre-zeroed by the caller) or NULL */
+} imt_beam_args;
+int imt_beam_step(const imt_beam_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

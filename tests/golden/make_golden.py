@@ -10,6 +10,12 @@
                   dropout off, seed fixed): inputs, state_dict, encoder states, log-probs, loss, selected grads,
                   three optimizer steps.  The reference's own tests pin nothing numeric for the model
                   (parity unpinned) -- this fixture guards the oracle against drift.
+* beam_kat.json : known-answer vectors from the REFERENCE's own src/seq_gen.py get_outputs_until_eos (imported
+                  from /root/reference/src): token matrices + eos / size_limit / remove_first_token -> cut rows.
+* toy_beam.pt   : beam-search token ids from THIS repo's oracle (oracle/seq_gen.py) on the toy model derived from
+                  toy_seq2seq.pt by tests/util.py:beam_state_dict (matrices x2, EOS bias) so that hypotheses finish
+                  at different steps; text (beam 1 / 4, with and without unpadding) and image-only captioning.
+                  The reference has no test or fixture for beam search (parity unpinned).
 """
 import json
 import os
@@ -85,7 +91,61 @@ def make_toy():
                os.path.join(HERE, "toy_seq2seq.pt"))
 
 
+def make_beam_kat():
+    sys.path.insert(0, "/root/reference/src")
+    import seq_gen as ref_gen  # the reference's own file (needs only torch)
+    g = torch.Generator().manual_seed(7)
+    cases = []
+    for rows, cols, eos, with_limit, rm_first in [(5, 9, 4, False, False), (6, 12, 4, True, False), (4, 7, 2, True, True),
+                                                  (1, 5, 4, False, True)]:
+        m = torch.randint(0, 8, (rows, cols), generator=g)
+        limit = torch.randint(2, cols + 1, (rows,), generator=g) if with_limit else None
+        out = ref_gen.get_outputs_until_eos(eos, m, size_limit=limit, remove_first_token=rm_first)
+        cases.append({"outputs": m.tolist(), "eos": eos, "size_limit": None if limit is None else limit.tolist(),
+                      "remove_first_token": rm_first, "expected": [o.tolist() for o in out]})
+    v = torch.tensor([5, 9, 4, 7, 4])
+    cases.append({"outputs": v.tolist(), "eos": 4, "size_limit": None, "remove_first_token": False,
+                  "expected": [o.tolist() for o in ref_gen.get_outputs_until_eos(4, v)]})
+    json.dump({"source": "rasoolims/ImageTranslate src/seq_gen.py get_outputs_until_eos", "cases": cases},
+              open(os.path.join(HERE, "beam_kat.json"), "w"), indent=1)
+
+
+def make_beam():
+    from oracle import reference_model as R
+    from oracle.seq_gen import BeamDecoder
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import beam_inputs, beam_state_dict, caption_beam_inputs
+    fx = torch.load(os.path.join(HERE, "toy_seq2seq.pt"), weights_only=True)
+    tp = R.SyntheticTextProcessor(1000)
+    m = R.Seq2Seq(tp, lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512, num_attention_heads=4)
+    m.load_state_dict(beam_state_dict(fx["state_dict"]))
+    m.eval()
+    inp = beam_inputs()
+    res = {}
+    for name, kw in [("beam4", dict(beam_width=4)), ("beam1", dict(beam_width=1)), ("beam3_padded", dict(beam_width=3, unpad_output=False)),
+                     ("beam4_maxlen10", dict(beam_width=4, max_len=10))]:
+        trace = []
+        out = BeamDecoder(m, beam_width=5)(pad_idx=0, trace=trace, **inp, **kw)
+        res[name] = {"tokens": [o.clone() for o in out], "steps": len(trace),
+                     "trace_outs": [t["outs"].clone() for t in trace]}
+    m.load_state_dict(beam_state_dict(fx["state_dict"], 2.5, 2.5))
+    res["beam4_soft"] = {"tokens": [o.clone() for o in BeamDecoder(m, beam_width=4)(pad_idx=0, **inp)]}
+    torch.manual_seed(4321)
+    cap = R.ImageCaptioning(tp, lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512,
+                            num_attention_heads=4, image_feat_dim=64)
+    extra = {k: v.clone() for k, v in cap.state_dict().items() if k not in fx["state_dict"]}
+    cap.load_state_dict({**beam_state_dict(fx["state_dict"]), **extra})
+    cap.eval()
+    out = BeamDecoder(cap, beam_width=3)(pad_idx=0, max_len=14, **caption_beam_inputs())
+    res["caption_beam3"] = {"tokens": [o.clone() for o in out], "extra_state": extra}
+    torch.save(res, os.path.join(HERE, "toy_beam.pt"))
+    for k, v in res.items():
+        print(k, [len(t) for t in v["tokens"]])
+
+
 if __name__ == "__main__":
     make_loss_kat()
     make_toy()
+    make_beam_kat()
+    make_beam()
     print("wrote", os.listdir(HERE))

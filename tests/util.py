@@ -18,3 +18,40 @@ def assert_close(a, b, tol, what=""):
 
 
 TOL = {torch.float32: 1e-4, torch.bfloat16: 2.5e-2}
+
+
+# ------------------------------------------------------------------------------------------- beam-search fixtures
+def beam_state_dict(sd, scale: float = 4.0, eos_bias: float = 5.0, eos: int = 4):
+    """Toy weights for beam search: the N(0, 0.02) fixture weights give near-uniform next-token distributions, so
+    matrices are scaled up and the EOS logit biased -- hypotheses then finish at different steps and the EOS /
+    length-limit / PAD bookkeeping of src/seq_gen.py:193-227 is exercised."""
+    out = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if v.dim() > 1 and v.is_floating_point():
+            v = v * scale
+        if k.startswith("output_layer") and k.endswith("layer.bias"):
+            v[eos] = eos_bias
+        out[k] = v
+    return out
+
+
+def beam_inputs():
+    B, S = 6, 12
+    g = torch.Generator().manual_seed(1)
+    src = torch.randint(6, 1000, (B, S), generator=g)
+    lens = torch.tensor([12, 10, 8, 12, 5, 7])
+    mask = torch.arange(S)[None, :] < lens[:, None]
+    src[~mask] = 0
+    src[:, 0] = 5
+    for b in range(B):
+        src[b, lens[b] - 1] = 4
+    return dict(src_inputs=src, src_sizes=lens, first_tokens=torch.full((B,), 5, dtype=torch.long), src_mask=mask,
+                src_langs=torch.zeros(B, dtype=torch.long), tgt_langs=torch.ones(B, dtype=torch.long))
+
+
+def caption_beam_inputs():
+    B = 5
+    g = torch.Generator().manual_seed(3)
+    return dict(images=torch.randn(B, 49, 64, generator=g), first_tokens=torch.full((B,), 5, dtype=torch.long),
+                tgt_langs=torch.ones(B, dtype=torch.long))

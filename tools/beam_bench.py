@@ -1,0 +1,40 @@
+"""Beam-search throughput on the C1 model shape (6+6 layers, d=512, V=30000): KV-cached incremental decoding vs
+the reference's per-step recomputation, both on the HIP path.  Usage: python tools/beam_bench.py [B] [S] [beam]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from bench import CONFIGS, build_model  # noqa: E402
+from imagetranslate_amd.seq_gen import BeamDecoder  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    beam = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    cfg = CONFIGS["c1"]
+    model = build_model(cfg, torch.bfloat16, torch.device("cuda")).eval()
+    g = torch.Generator().manual_seed(1234)
+    src = torch.randint(6, cfg["V"], (B, S), generator=g)
+    src[:, 0] = 5
+    src[:, -1] = 4
+    mask = torch.ones(B, S, dtype=torch.bool)
+    args = dict(src_inputs=src.cuda(), src_sizes=torch.full((B,), S), first_tokens=torch.full((B,), 5), src_mask=mask.cuda(),
+                src_langs=torch.zeros(B, dtype=torch.long).cuda(), tgt_langs=torch.ones(B, dtype=torch.long).cuda(), pad_idx=0)
+    for kv, max_len in ((True, None), (False, None)):
+        dec = BeamDecoder(model, beam_width=beam, kv_cache=kv)
+        out = dec(max_len=8, **args)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = dec(max_len=max_len, **args)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        n = sum(len(o) for o in out)
+        print("kv_cache=%s B=%d S=%d beam=%d: %.3f s, %d output tokens, %.0f tok/s, %.2f ms/step" %
+              (kv, B, S, beam, dt, n, n / dt, 1e3 * dt / max(len(o) for o in out)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
