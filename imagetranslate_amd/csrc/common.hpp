@@ -77,6 +77,8 @@ template <> struct Vec4<float> {
   typedef f32x4 type;
   static IMT_DEVICE f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static IMT_DEVICE void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  static IMT_DEVICE type load_raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }  // no conversion: the
+  static IMT_DEVICE f32x4 cvt(type v) { return v; }                                                // load stays in flight
 };
 template <> struct Vec4<bf16_t> {
   typedef bf16x4 type;
@@ -88,6 +90,11 @@ template <> struct Vec4<bf16_t> {
   static IMT_DEVICE void store(bf16_t* p, f32x4 v) {
     bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
     *reinterpret_cast<bf16x4*>(p) = r;
+  }
+  static IMT_DEVICE type load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static IMT_DEVICE f32x4 cvt(type v) {
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
   }
 };
 

@@ -187,8 +187,29 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* resid = reinterpret_cast<const T*>(ep.resid);
   T* aux = reinterpret_cast<T*>(ep.aux);
+  // bf16: the aux (GELU') / residual / bias operands of a pass are requested BEFORE the tile is restaged through LDS, as
+  // raw 8-byte loads that stay in flight across the two barriers (converted only where used); read inside the group
+  // loop each would be a dependent global-load latency per group (tools/gemm_epi.py: +24 us on 8192x2048x512).
+  typedef typename Vec4<T>::type raw_t;
+  constexpr bool PREFETCH = (sizeof(T) == 2);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
+    raw_t zr[8], rr[8], br = raw_t{};
+    const bool pre = PREFETCH && active && !ep.atomic && (m0 + 64 * pass + 64 <= M) && (n0 + BN <= N);
+    if (PREFETCH) {
+#pragma unroll
+      for (int gq = 0; gq < 8; ++gq) { zr[gq] = raw_t{}; rr[gq] = raw_t{}; }
+      if (pre) {
+        const int c4 = threadIdx.x & 31;
+        if (bias) br = Vec4<T>::load_raw(bias + n0 + 4 * c4);
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {
+          const int64_t m = m0 + 64 * pass + ((gq * NTHREADS + (int)threadIdx.x) >> 5);
+          if (ep.aux_mode == IMT_AUX_DGELU) zr[gq] = Vec4<T>::load_raw(aux + m * ep.ldaux + n0 + 4 * c4);
+          if (resid) rr[gq] = Vec4<T>::load_raw(resid + m * ep.ldr + n0 + 4 * c4);
+        }
+      }
+    }
     __syncthreads();  // previous users of smem (K loop / previous pass) are done
     if (active && wm == 64 * pass) {
 #pragma unroll
@@ -214,13 +235,13 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
         continue;
       }
       if (n + 3 < N) {
-        if (bias) v += Vec4<T>::load(bias + n);
+        if (bias) v += pre ? Vec4<T>::cvt(br) : Vec4<T>::load(bias + n);
         if (ep.aux_mode == IMT_AUX_GELU_FWD) {
           Vec4<T>::store(aux + (int64_t)m * ep.ldaux + n, v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         } else if (ep.aux_mode == IMT_AUX_DGELU) {
-          const f32x4 z = Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
+          const f32x4 z = pre ? Vec4<T>::cvt(zr[gq]) : Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
         }
@@ -229,7 +250,7 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
           for (int e = 0; e < 4; ++e)
             v[e] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? v[e] * ep.inv_keep : 0.f;
         }
-        if (resid) v += Vec4<T>::load(resid + (int64_t)m * ep.ldr + n);
+        if (resid) v += pre ? Vec4<T>::cvt(rr[gq]) : Vec4<T>::load(resid + (int64_t)m * ep.ldr + n);
         if (ep.c_f32) {
           float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
           if (ep.accumulate) v += Vec4<float>::load(c);

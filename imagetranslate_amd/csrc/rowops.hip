@@ -60,17 +60,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // ------------------------------------------------------------------------------------------- LayerNorm bwd
-// Each wave walks `rows_per_wave` rows, keeps per-column partial dgamma/dbeta in registers, the 4 waves of
+// Each wave walks `rows_per_wave` rows, keeps per-column partial dgamma/dbeta in registers, the WPB waves of
 // a block combine through LDS and issue one fp32 atomic per column per block.
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int NCH, int WPB>
+__global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                      int d, int rows_per_wave, uint32_t y_thresh, float y_inv_keep,
                                                      uint64_t y_seed, T* __restrict__ dx_drop, uint32_t dx_thresh,
-                                                     float dx_inv_keep, uint64_t dx_seed, float* __restrict__ partial) {
-  __shared__ float red[2][ROWS_PER_BLOCK][NCH * 256];
+                                                     float dx_inv_keep, uint64_t dx_seed) {
+  __shared__ float red[2][WPB][NCH * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   f32x4 g[NCH], ag[NCH], ab[NCH];
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int row_begin = (imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + w) * rows_per_wave;
+  const int row_begin = (imt_xcd_block(blockIdx.x, gridDim.x) * WPB + w) * rows_per_wave;
   // rows are processed in batches of RB: all loads of a batch are issued before the first reduction, so a wave keeps
   // 2*RB row loads in flight (with ~1 wave per SIMD the row loop is otherwise a chain of exposed memory latencies)
   constexpr int RB = 4;
@@ -155,34 +155,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       red[1][w][i * 256 + lane * 4 + e] = ab[i][e];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
+  for (int c = threadIdx.x; c < d; c += WPB * 64) {
     float sg = 0.f, sb = 0.f;
 #pragma unroll
-    for (int k = 0; k < ROWS_PER_BLOCK; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
-    if (partial) {  // two-stage: plain coalesced stores, summed by ln_bwd_reduce_kernel (no same-address atomics storm)
-      partial[((int64_t)blockIdx.x * 2 + 0) * d + c] = sg;
-      partial[((int64_t)blockIdx.x * 2 + 1) * d + c] = sb;
-    } else {
-      atomicAdd(dgamma + c, sg);
-      atomicAdd(dbeta + c, sb);
-    }
+    for (int k = 0; k < WPB; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
   }
-}
-
-// stage 2: dgamma[c] += sum_b partial[b][0][c] ; dbeta likewise.  grid (ceil(d/256), slices): each thread sums one
-// slice of the block partials (coalesced across threads) and issues one atomic -> `slices` adds per address.
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int d,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d) return;
-  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
-  float sg = 0.f, sb = 0.f;
-  for (int b = b0; b < b1; ++b) {
-    sg += partial[((int64_t)b * 2 + 0) * d + c];
-    sb += partial[((int64_t)b * 2 + 1) * d + c];
-  }
-  if (b1 > b0) { atomicAdd(dgamma + c, sg); atomicAdd(dbeta + c, sb); }
 }
 
 // ------------------------------------------------------------------------------------------- embeddings
@@ -332,23 +311,28 @@ template <typename T, int NCH>
 int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, void* dx,
                   float* dgamma, float* dbeta, int rows, int d, float yp, uint64_t yseed, void* dx_drop, float dxp,
                   uint64_t dxseed, float* partial, hipStream_t st) {
-  // ~256 workgroups: the per-workgroup tail (LDS combine + one fp32 atomic per column) is what costs; measured sweep
-  // on MI355X at rows=8192, d=512: 2048 blocks 57 us, 1024: 33, 512: 23, 256: 22, 128: 30 (profiles/r01_ln_bwd_sweep.txt)
-  int rpw = imt_cdiv(rows, 256 * ROWS_PER_BLOCK);
+  // Every workgroup ends with one fp32 atomic per column (dgamma, dbeta), and that tail is what costs, so the
+  // grid stays at ~256 workgroups; the row phase gets its memory-level parallelism from WPB waves per workgroup
+  // instead (sweeps: profiles/r01_ln_bwd_sweep.txt; 8 waves x 256 workgroups: 17 us at rows=8192, d=512, of which the
+  // row phase alone is 11.5 us).
+  int wpb = 8;
+  if (const char* e = getenv("IMT_LN_WPB")) wpb = atoi(e);  // tuning hook: 4 | 8 | 16
+  int nblk = 256;
+  if (const char* e = getenv("IMT_LN_BLOCKS")) nblk = atoi(e) > 0 ? atoi(e) : nblk;
+  int rpw = imt_cdiv(rows, nblk * wpb);
   if (rpw < 1) rpw = 1;
-  if (const char* e = getenv("IMT_LN_RPW")) rpw = atoi(e) > 0 ? atoi(e) : rpw;  // tuning hook
-  const int blocks = imt_cdiv(rows, rpw * ROWS_PER_BLOCK);
+  const int blocks = imt_cdiv(rows, rpw * wpb);
   ImtProfScope prof("layernorm_bwd", 0.0, (dx_drop ? 4.0 : 3.0) * rows * d * sizeof(T), st);
-  hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x,
-                     (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),
-                     yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),
-                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed, partial);
+#define IMT_LN_BWD_LAUNCH(W)                                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, W>), dim3(blocks), dim3(W * 64), 0, st, (const T*)dy, (const T*)x,        \
+                     (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),            \
+                     yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),                      \
+                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed)
+  if (wpb == 4) IMT_LN_BWD_LAUNCH(4);
+  else if (wpb == 8) IMT_LN_BWD_LAUNCH(8);
+  else IMT_LN_BWD_LAUNCH(16);
+#undef IMT_LN_BWD_LAUNCH
   IMT_CHECK_LAUNCH();
-  if (partial) {
-    ImtProfScope prof2("layernorm_bwd_reduce", 0.0, 8.0 * blocks * d, st);
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(imt_cdiv(d, 256), 16), dim3(256), 0, st, partial, blocks, d, dgamma, dbeta);
-    IMT_CHECK_LAUNCH();
-  }
   return IMT_OK;
 }
 

@@ -116,8 +116,10 @@ int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamm
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
                       float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
                       uint64_t dx_dropout_seed, float* partial_ws, void* stream);
-/* partial_ws (nullable): IMT_LN_BWD_WS_FLOATS(d) floats of scratch; when given, dgamma/dbeta are reduced in two
- * stages (per-workgroup partials + a small reduce kernel) instead of one fp32 atomic per column per workgroup. */
+/* partial_ws: RESERVED, pass NULL (ignored).  Two alternatives to the per-workgroup atomics were built and measured
+ * slower on MI355X at rows=8192, d=512 (profiles/r01_ln_bwd_sweep.txt): per-workgroup partials + a reduce kernel
+ * (second launch), and a same-launch "last workgroup of a group sums its group" reduction (the device-scope release
+ * fence it needs writes back the XCD's L2: 48-140 us vs 21 us). */
 #define IMT_LN_BWD_WS_FLOATS(d) (1024 * 2 * (int64_t)(d))
 
 /* ------------------------------------------------------------------ embeddings (HF BertEmbeddings)

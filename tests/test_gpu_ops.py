@@ -163,6 +163,47 @@ def test_gemm_pipelined_vs_general_kernel(cuda, dtype, layout):
         assert torch.equal(outs[3], ref), "wave-specialised kernel wrong"
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues_agree_across_kernel_variants(cuda, dtype, layout):
+    """Every kernel variant (single buffer, register double buffer, persistent wave-specialised with several tiles
+    per workgroup) must produce BIT-IDENTICAL results for every epilogue the train step uses, on ragged M / N."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(21)
+    bk = 64 if dtype == torch.bfloat16 else 32
+    for (M, N, nk) in [(128 * 19 + 40, 128 * 15 + 72, 4), (300, 520, 9), (128 * 34, 256, 17)]:
+        K = nk * bk
+        A = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(cuda)
+        B = (torch.randn((N, K) if layout == O.IMT_NT else (K, N), generator=g) * 0.5).to(dtype).to(cuda)
+        bias = torch.randn(N, generator=g).to(dtype).to(cuda)
+        resid = torch.randn(M, N, generator=g).to(dtype).to(cuda)
+        z = torch.randn(M, N, generator=g).to(dtype).to(cuda)
+        cases = [dict(), dict(bias=bias), dict(bias=bias, aux_mode=O.IMT_AUX_GELU_FWD), dict(aux_mode=O.IMT_AUX_DGELU),
+                 dict(bias=bias, dropout_p=0.1, dropout_seed=77, resid=resid), dict(resid=resid), dict(alpha=0.25, resid=resid)]
+        for kw in cases:
+            outs, auxs = [], []
+            for force in (3, 1, 5):
+                aux = None
+                if kw.get("aux_mode") == O.IMT_AUX_GELU_FWD:
+                    aux = torch.zeros(M, N, device=cuda, dtype=dtype)
+                elif kw.get("aux_mode") == O.IMT_AUX_DGELU:
+                    aux = z
+                out = torch.zeros(M, N, device=cuda, dtype=dtype)
+                O.gemm(A, B, layout, out=out, aux=aux, force_general=force, **kw)
+                outs.append(out.float().cpu())
+                auxs.append(None if aux is None else aux.float().cpu())
+            for o in outs[1:]:
+                assert torch.equal(outs[0], o), "epilogue %s differs (max %g)" % (sorted(kw), float((outs[0] - o).abs().max()))
+            for x in auxs[1:]:
+                assert auxs[0] is None or torch.equal(auxs[0], x)
+        # fp32 output with accumulate (the form the runtime uses for C += ...)
+        c0 = torch.randn(M, N, generator=g).to(cuda)
+        o3, o5 = c0.clone(), c0.clone()
+        O.gemm(A, B, layout, out=o3, accumulate=True, force_general=3)
+        O.gemm(A, B, layout, out=o5, accumulate=True, force_general=5)
+        assert torch.equal(o3.cpu(), o5.cpu())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_tn_fused_bias_gradient(cuda, dtype):
     from imagetranslate_amd import hip_ops as O
