@@ -750,6 +750,24 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   const int64_t a_rows = (a->layout == IMT_TN) ? a->K : a->M, b_rows = (a->layout == IMT_NT) ? a->N : a->K;
   const bool pipe_ok = (a->K % bk == 0) && (a->K / bk >= 2) && (a_rows * a->lda * es < (1ll << 31)) &&
                        (b_rows * a->ldb * es < (1ll << 31));
+  // Long K that is not a whole number of tiles (the vocabulary dimension: dX = dlogits[.,30000] W): the LDS-DMA
+  // kernels need whole K tiles, so the ragged tail goes first as its own small product and the whole-tile body is
+  // accumulated on top by the persistent kernel (477 -> ~700 TFLOP/s on 8128x512x30000).  Only for epilogues that are
+  // linear in the product (bias / residual ride on the tail call).
+  if (a->force_general == 0 && splits == 1 && a->K % bk != 0 && a->K / bk >= 16 && a->aux_mode == IMT_AUX_NONE &&
+      a->dropout_p == 0.f && !a->a_colsum) {
+    const int kb = (a->K / bk) * bk, kt = a->K - kb;
+    imt_gemm_args tail = *a, body = *a;
+    const int64_t a_off = (a->layout == IMT_TN) ? (int64_t)kb * a->lda : kb;
+    const int64_t b_off = (a->layout == IMT_NT) ? kb : (int64_t)kb * a->ldb;
+    tail.K = kt;
+    tail.A = reinterpret_cast<const char*>(a->A) + a_off * es;
+    tail.B = reinterpret_cast<const char*>(a->B) + b_off * es;
+    body.K = kb; body.accumulate = 1; body.bias = nullptr; body.resid = nullptr;
+    const int rc = imt_gemm(&tail, stream);
+    if (rc != IMT_OK) return rc;
+    return imt_gemm(&body, stream);
+  }
   const int64_t nblocks = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN) * splits;
   // kernel variant: 1 = register-staged double buffer (2 blocks/CU), 2 = LDS-DMA 3-stage ring (1 block/CU),
   // 3 = single buffer + register prefetch (4 blocks/CU).  a->force_general carries a variant code for tests/tuning.

@@ -1,6 +1,7 @@
 // Vocabulary-row kernels: log-softmax (src/seq2seq.py:179-180), label-smoothed NLL (src/loss.py:10-27) and the
 // fused cross-entropy forward+backward used by the training fast path.  One 256-thread workgroup per row;
 // a row (V = 30k..60k logits) is streamed with 8/16-byte loads and reduced with wave + LDS reductions.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -144,6 +145,73 @@ __global__ __launch_bounds__(256) void xent_fused_kernel(T* __restrict__ logits,
     z[c] = from_f32<T>(gs * (__expf(to_f32<T>(z[c]) - lse) - sm - ((c == t) ? (1.f - eps) : 0.f)));
 }
 
+// bf16 rows are small enough (V = 30000 -> 60 KB) to park in LDS: the row is read from HBM ONCE (while taking the
+// maximum), the exp-sum and the gradient pass read the LDS copy, and dlogits is written once -- 2 x N x V x 2 bytes of
+// HBM traffic instead of 4 x (profiles/r01_pmc_traffic.json showed 1.95 GB for the three-read version).
+__global__ __launch_bounds__(256) void xent_fused_lds_kernel(bf16_t* __restrict__ logits, int64_t ld,
+                                                             const int64_t* __restrict__ target, float* __restrict__ loss_rows,
+                                                             int V, float eps, int64_t ignore_index, float grad_scale) {
+  extern __shared__ __attribute__((aligned(16))) char row_s[];
+  __shared__ float red[4];
+  bf16_t* zs = reinterpret_cast<bf16_t*>(row_s);
+  const int64_t row = imt_xcd_block(blockIdx.x, gridDim.x);
+  bf16_t* z = logits + row * ld;
+  const int64_t t = target[row];
+  const bool ignored = (t == ignore_index);
+  const int V8 = V & ~7;
+  float m = -INFINITY, sumz = 0.f;
+  // 8 independent 16-byte loads per thread in flight (a plain loop would pay one HBM latency per iteration)
+  constexpr int UNR = 8;
+  for (int c0 = threadIdx.x * 8; c0 < V8; c0 += 2048 * UNR) {
+    bf16x8 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int c = c0 + u * 2048;
+      if (c < V8) v[u] = *reinterpret_cast<const bf16x8*>(z + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int c = c0 + u * 2048;
+      if (c < V8) {
+        *reinterpret_cast<bf16x8*>(zs + c) = v[u];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; m = fmaxf(m, f); sumz += f; }
+      }
+    }
+  }
+  for (int c = V8 + threadIdx.x; c < V; c += 256) { const bf16_t v = z[c]; zs[c] = v; m = fmaxf(m, (float)v); sumz += (float)v; }
+  const float mx = block_max(m, red);  // (barrier inside: the LDS copy is complete)
+  float s = 0.f;
+  for (int c = threadIdx.x * 8; c < V8; c += 2048) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(zs + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += __expf((float)v[e] - mx);
+  }
+  for (int c = V8 + threadIdx.x; c < V; c += 256) s += __expf((float)zs[c] - mx);
+  const float se = block_sum(s, red);
+  const float sz = block_sum(sumz, red);
+  const float lse = mx + __logf(se);
+  if (threadIdx.x == 0) {
+    float out = 0.f;
+    if (!ignored) {
+      const float zt = (t >= 0 && t < V) ? (float)zs[t] : lse;
+      out = (1.f - eps) * (lse - zt) + (eps / (float)V) * ((float)V * lse - sz);
+    }
+    loss_rows[row] = out;
+  }
+  const float gs = ignored ? 0.f : grad_scale;
+  const float sm = eps / (float)V;
+  for (int c = threadIdx.x * 8; c < V8; c += 2048) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(zs + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(gs * (__expf((float)v[e] - lse) - sm - ((c + e == t) ? (1.f - eps) : 0.f)));
+    *reinterpret_cast<bf16x8*>(z + c) = o;
+  }
+  for (int c = V8 + threadIdx.x; c < V; c += 256)
+    z[c] = (bf16_t)(gs * (__expf((float)zs[c] - lse) - sm - ((c == t) ? (1.f - eps) : 0.f)));
+}
+
 }  // namespace
 
 extern "C" int imt_log_softmax_fwd(int dtype, const void* logits, int64_t ld, float* lp, int64_t ldlp, float* lse, int N,
@@ -200,9 +268,17 @@ extern "C" int imt_xent_fused_fwd_bwd(int dtype, void* logits, int64_t ld, const
   IMT_CHECK_ARG(logits && target && loss_rows && V > 0 && ld % 4 == 0, "xent_fused: bad args");
   hipStream_t st = (hipStream_t)stream;
   ImtProfScope prof("xent_fused", 0.0, 2.0 * N * V * (dtype == IMT_BF16 ? 2 : 4), st);
-  if (dtype == IMT_F32)
+  const int row_bytes = ((V * 2 + 15) / 16) * 16;
+  if (dtype == IMT_F32) {
     hipLaunchKernelGGL(xent_fused_kernel<float>, dim3(N), dim3(256), 0, st, (float*)logits, ld, target, loss_rows, V, epsilon, ignore_index, grad_scale);
-  else
+  } else if (row_bytes <= 128 * 1024 && ld % 8 == 0 && !getenv("IMT_XENT_NO_LDS")) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xent_fused_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(xent_fused_lds_kernel, dim3(N), dim3(256), row_bytes, st, (bf16_t*)logits, ld, target, loss_rows, V, epsilon, ignore_index, grad_scale);
+  } else
     hipLaunchKernelGGL(xent_fused_kernel<bf16_t>, dim3(N), dim3(256), 0, st, (bf16_t*)logits, ld, target, loss_rows, V, epsilon, ignore_index, grad_scale);
   IMT_CHECK_LAUNCH();
   return IMT_OK;

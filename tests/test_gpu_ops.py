@@ -204,6 +204,34 @@ def test_gemm_epilogues_agree_across_kernel_variants(cuda, dtype, layout):
         assert torch.equal(o3.cpu(), o5.cpu())
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_long_ragged_k_split(cuda, dtype, layout):
+    """K >= 16 tiles but not a whole number of tiles (the vocabulary dimension): imt_gemm runs the ragged tail and
+    the whole-tile body as two launches; result == one product, including bias / residual / accumulate / alpha."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(31)
+    bk = 64 if dtype == torch.bfloat16 else 32
+    M, N, K = 264, 200, 17 * bk + 24
+    A = torch.randint(-2, 3, (M, K), generator=g).float()
+    B = torch.randint(-2, 3, (N, K), generator=g).float()
+    ref = A @ B.t()
+    a_in, b_in = (A, B) if layout == O.IMT_NT else ((A, B.t().contiguous()) if layout == O.IMT_NN else (A.t().contiguous(), B.t().contiguous()))
+    da, db = a_in.to(dtype).to(cuda), b_in.to(dtype).to(cuda)
+    out = torch.zeros(M, N, device=cuda, dtype=torch.float32)
+    O.gemm(da, db, layout, out=out)
+    assert torch.equal(out.cpu(), ref), "plain product (integer data, exact)"
+    c0 = torch.randint(-5, 6, (M, N), generator=g).float()
+    out = c0.clone().to(cuda)
+    O.gemm(da, db, layout, out=out, accumulate=True, alpha=0.5)
+    assert torch.equal(out.cpu(), c0 + 0.5 * ref), "alpha + accumulate"
+    if layout != O.IMT_TN:
+        bias = torch.randint(-3, 4, (N,), generator=g).float()
+        resid = torch.randint(-3, 4, (M, N), generator=g).float()
+        out = O.gemm(da, db, layout, bias=bias.to(dtype).to(cuda), resid=resid.to(dtype).to(cuda), out_dtype=torch.float32)
+        assert torch.equal(out.cpu(), ref + bias + resid), "bias + residual applied exactly once"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_tn_fused_bias_gradient(cuda, dtype):
     from imagetranslate_amd import hip_ops as O
