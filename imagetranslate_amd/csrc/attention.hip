@@ -85,7 +85,7 @@ template <> struct AccOperand<bf16_t> {
 
 // =========================================================================================== forward
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
   constexpr int NSUB = (RB > 128) ? 1 : 2;  // 64-row sub-tiles staged per barrier pair (LDS budget)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 
 // =========================================================================================== backward: dQ
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
   constexpr int NSUB = (RB > 128) ? 1 : 2;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 
 // =========================================================================================== backward: dK, dV
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (DH == 64 && sizeof(T) == 2) ? 3 : 2) void attn_bwd_dkdv_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
   constexpr int NSUB = (RB > 128) ? 1 : 2;
