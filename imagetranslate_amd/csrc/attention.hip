@@ -12,6 +12,7 @@
 //   dK/dV     : one workgroup = 64 keys; KEY on the lane (S = Q K^T), dV^T / dK^T accumulate in registers over
 //               all query tiles; Q and dO tiles are staged once and read both row-wise and transposed.
 // Nothing is summed across workgroups: no atomics, bitwise reproducible.
+#include <stdlib.h>
 #include "mma.hpp"
 
 namespace {
@@ -442,6 +443,170 @@ __global__ __launch_bounds__(256, (DH == 64 && sizeof(T) == 2) ? 3 : 2) void att
   }
 }
 
+// =========================================================================================== backward, short sequences
+// Tq, Tk <= 128 (the C1 workload: S = T = 128), bf16: ONE workgroup (8 waves) per (batch, head) computes dQ, dK and
+// dV together.  The two-kernel path above recomputes S and dP twice, reads Q/K/V/dO/O twice and pays two dependent
+// load->compute->store latency chains per attention block; here
+//   phase 0: Q and dO (all <= 128 rows) are staged once, delta = rowsum(dO * O) is taken from the row fragments;
+//   phase 1: KEY on the lane (wave w owns keys 16w..16w+15, K/V rows in registers): S, P, dP, dS for all queries;
+//            dV^T += dO^T P and dK^T += Q^T dS accumulate in registers; dS^T goes to LDS as bf16 [key][query];
+//   phase 2: QUERY on the lane (wave w owns queries 16w..): dQ = dS K as a plain K-strided x K-strided product from
+//            LDS (dS^T tile, and K parked into the region Q occupied).
+// Nothing is summed across workgroups; same dropout mask / mask semantics as the kernels above.
+template <int DH>
+__global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
+  typedef bf16_t T;
+  constexpr int RB = DH * 2, NS = RB / 64, NDT = DH / 16;
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;                        // [128][RB]  (phase 2: K)
+  char* dOs = Qs + 128 * RB;              // [128][RB]
+  char* dST = dOs + 128 * RB;             // [128 keys][128 queries] bf16, 256-B rows
+  float* lse_s = reinterpret_cast<float*>(dST + 128 * 256);
+  float* delta_s = lse_s + 128;
+  uint8_t* qmask_s = reinterpret_cast<uint8_t*>(delta_s + 128);
+
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);
+  const int b = lid / p.H, h = lid % p.H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)b * p.Tq * p.lddo + h * DH;
+  const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)b * p.Tq * p.ldo + h * DH;
+
+  // ---- phase 0
+  {
+    constexpr int CPR = RB / 16;
+    for (int q = threadIdx.x; q < 128 * CPR; q += 512) {
+      const int tr = q / CPR, c = q % CPR;
+      u32x4 vq = {0u, 0u, 0u, 0u}, vo = {0u, 0u, 0u, 0u};
+      if (tr < p.Tq) {
+        vq = *reinterpret_cast<const u32x4*>(Qb + (int64_t)tr * p.ldq + c * 8);
+        vo = *reinterpret_cast<const u32x4*>(dOb + (int64_t)tr * p.lddo + c * 8);
+      }
+      *reinterpret_cast<u32x4*>(Qs + tile_off<RB>(tr, c)) = vq;
+      *reinterpret_cast<u32x4*>(dOs + tile_off<RB>(tr, c)) = vo;
+    }
+    const int i = 16 * wave + r;  // delta / lse of this wave's 16 query rows
+    frag_t of[NS], dof[NS];
+    load_row_frags<T, DH>(of, Ob, p.ldo, 16 * wave, p.Tq);
+    load_row_frags<T, DH>(dof, dOb, p.lddo, 16 * wave, p.Tq);
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += (float)dof[ks][e] * (float)of[ks][e];
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    if (g == 0) {
+      delta_s[i] = d;
+      lse_s[i] = p.lse[((int64_t)b * p.H + h) * p.Tq + (i < p.Tq ? i : 0)];
+      qmask_s[i] = (i < p.Tq && p.query_mask) ? p.query_mask[(int64_t)b * p.Tq + i] : (uint8_t)1;
+    }
+  }
+  const int k0 = 16 * wave;
+  const int j = k0 + r;  // this lane's key (phase 1)
+  frag_t kf[NS], vf[NS];
+  load_row_frags<T, DH>(kf, Kb, p.ldk, k0, p.Tk);
+  load_row_frags<T, DH>(vf, Vb, p.ldv, k0, p.Tk);
+  const bool key_ok = (j < p.Tk) ? (p.key_mask ? (p.key_mask[(int64_t)b * p.Tk + j] != 0) : true) : false;
+  __syncthreads();
+
+  // ---- phase 1
+  f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int nqt = (p.Tq + 63) / 64;
+#pragma unroll 1
+  for (int qt = 0; qt < 2; ++qt) {
+    const char* Qt = Qs + qt * 64 * RB;
+    const char* dOt = dOs + qt * 64 * RB;
+    f32x4 s[4], dp[4], pd[4];
+    if (qt < nqt) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        s[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          mma16(s[mt], lds_frag_kcontig<T, RB>(Qt, 16 * mt, 4 * ks), kf[ks]);
+          mma16(dp[mt], lds_frag_kcontig<T, RB>(dOt, 16 * mt, 4 * ks), vf[ks]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = qt * 64 + 16 * mt + 4 * g + e;
+          float v = s[mt][e] * p.scale + (mask_ok(p, b, i, j, key_ok, qmask_s[i] != 0) ? 0.f : -10000.0f);
+          float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_s[i]) : 0.f;
+          float dpv = dp[mt][e], pdv = pv;
+          if (p.drop_thresh) {
+            const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
+            const bool keep = dropout_keep(p.seed, idx, p.drop_thresh);
+            dpv = keep ? dpv * p.inv_keep : 0.f;
+            pdv = keep ? pv * p.inv_keep : 0.f;
+          }
+          pd[mt][e] = pdv;
+          s[mt][e] = pv * (dpv - delta_s[i]);  // dS[i][j]
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const frag_t pf = acc_pair_to_frag(pd[2 * u], pd[2 * u + 1]);
+        const frag_t dsf = acc_pair_to_frag(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          mma16(dv[dt], lds_frag_kperm_bf16<RB>(dOt, 32 * u, 16 * dt), pf);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+          mma16(dk[dt], lds_frag_kperm_bf16<RB>(Qt, 32 * u, 16 * dt), dsf);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) s[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // dS^T[key j][queries 64qt + 16mt + 4g .. +3] (bf16, 8 bytes)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int q_first = qt * 64 + 16 * mt + 4 * g;
+      bf16x4 w = {(bf16_t)s[mt][0], (bf16_t)s[mt][1], (bf16_t)s[mt][2], (bf16_t)s[mt][3]};
+      *reinterpret_cast<bf16x4*>(dST + tile_off<256>(j, q_first >> 3) + ((q_first & 7) << 1)) = w;
+    }
+  }
+  if (j < p.Tk) {
+    T* dKb = reinterpret_cast<T*>(p.dK) + ((int64_t)b * p.Tk + j) * p.lddk + h * DH;
+    T* dVb = reinterpret_cast<T*>(p.dV) + ((int64_t)b * p.Tk + j) * p.lddv + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      Vec4<T>::store(dKb + 16 * dt + 4 * g, dk[dt] * p.scale);
+      Vec4<T>::store(dVb + 16 * dt + 4 * g, dv[dt]);
+    }
+  }
+  __syncthreads();  // every wave is done with Q / dO; dS^T is complete
+  char* Ks = Qs;
+#pragma unroll
+  for (int ks = 0; ks < NS; ++ks) *reinterpret_cast<frag_t*>(Ks + tile_off<RB>(k0 + r, 4 * ks + g)) = kf[ks];
+  __syncthreads();
+
+  // ---- phase 2: dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
+  f32x4 dq[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nks = (p.Tk + 31) / 32;
+#pragma unroll 1
+  for (int kstep = 0; kstep < nks; ++kstep) {
+    const frag_t fa = lds_frag_kstrided_bf16<256>(dST, 32 * kstep, 16 * wave);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) mma16(dq[dt], lds_frag_kstrided_bf16<RB>(Ks, 32 * kstep, 16 * dt), fa);
+  }
+  const int i = 16 * wave + r;
+  if (i < p.Tq) {
+    T* dQb = reinterpret_cast<T*>(p.dQ) + ((int64_t)b * p.Tq + i) * p.lddq + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(dQb + 16 * dt + 4 * g, dq[dt] * p.scale);
+  }
+}
+
 int check_args(const imt_attn_args* a, bool bwd) {
   IMT_CHECK_ARG(a != nullptr, "attention: null args");
   IMT_CHECK_ARG(a->dtype == IMT_F32 || a->dtype == IMT_BF16, "attention: bad dtype");
@@ -482,6 +647,20 @@ template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
+template <int DH> int bwd_fused_launch(const AttnP& p, hipStream_t st) {
+  const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
+  const double io = ((double)p.B * p.H * DH * 2.0) * (4.0 * p.Tq + 4.0 * p.Tk);
+  const int lds = 2 * 128 * DH * 2 + 128 * 256 + 128 * 4 * 2 + 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  ImtProfScope prof("attn_bwd_fused_bf16", 10.0 * work, io, st);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<DH>), dim3(p.B * p.H), dim3(512), lds, st, p);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
 template <typename T, int DH> int bwd_launch(const AttnP& p, hipStream_t st) {
   const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
   const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
@@ -515,5 +694,7 @@ extern "C" int imt_attention_bwd(const imt_attn_args* a, void* stream) {
   const AttnP p = make_params(a);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == IMT_F32) return a->head_dim == 32 ? bwd_launch<float, 32>(p, st) : bwd_launch<float, 64>(p, st);
+  if (a->Tq <= 128 && a->Tk <= 128 && !getenv("IMT_ATTN_NO_FUSED_BWD"))  // short sequences: one fused kernel
+    return a->head_dim == 32 ? bwd_fused_launch<32>(p, st) : bwd_fused_launch<64>(p, st);
   return a->head_dim == 32 ? bwd_launch<bf16_t, 32>(p, st) : bwd_launch<bf16_t, 64>(p, st);
 }
