@@ -351,7 +351,7 @@ class _LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         store = ctx.store
         N, K = ctx.shape
-        dy = dy.to(x.dtype).contiguous()
+        dy = O.rows16(dy.to(x.dtype))  # [M, out_features]: rows stay 16-byte aligned for any vocabulary size
         M = dy.shape[0]
         dx = O.gemm(dy, w, O.IMT_NN) if ctx.needs_input_grad[0] else None
         gw = store.grad[ctx.wo:ctx.wo + N * K].view(N, K)

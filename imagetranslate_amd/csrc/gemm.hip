@@ -730,7 +730,16 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   // contiguous extents of the vector loads must be chunk multiples
   const int a_inner = (a->layout == IMT_TN) ? a->M : a->K;
   const int b_inner = (a->layout == IMT_NT) ? a->K : a->N;
-  IMT_CHECK_ARG(a_inner % al == 0 && b_inner % al == 0, "imt_gemm: inner extents (%d,%d) must be multiples of %d",
+  // A contiguous extent that is not a whole number of 16-byte chunks (a vocabulary of 193 entries ...) is accepted when
+  // the leading dimension covers the rounded-up extent (the last chunk of a row then stays inside the row's storage)
+  // and what the overhang reads cannot reach the result: output rows/columns past M/N are masked by the epilogue, and
+  // the K overhang of the K-contiguous A of NN meets zero-filled B rows.  Both operands of NT share the K overhang,
+  // so NT keeps the strict rule.
+  const auto extent_ok = [al](int inner, int64_t ld, bool strict) {
+    return inner % al == 0 || (!strict && ld >= (int64_t)((inner + al - 1) / al) * al);
+  };
+  IMT_CHECK_ARG(extent_ok(a_inner, a->lda, a->layout == IMT_NT) && extent_ok(b_inner, a->ldb, a->layout == IMT_NT),
+                "imt_gemm: contiguous extents (%d,%d) must be multiples of %d (or, for NN/TN, padded by the leading dimension)",
                 a_inner, b_inner, al);
   IMT_CHECK_ARG(a->ldc % 4 == 0, "imt_gemm: ldc must be a multiple of 4");
   const int c_f32 = (a->c_dtype == IMT_F32);

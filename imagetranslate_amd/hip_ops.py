@@ -33,6 +33,26 @@ def _req_cuda(*ts):
             raise L.ImtError("imagetranslate_amd HIP ops need tensors on the GPU (no CPU fallback)")
 
 
+def alloc_rows(n_rows, width, dtype, device):
+    """[n_rows, width] view of a zero-initialised buffer whose leading dimension is rounded up to 8 elements: rows stay
+    16-byte aligned for the vector loads/stores when ``width`` (e.g. a tokenizer's vocabulary size) is not a multiple
+    of 8, and the pad columns hold zeros."""
+    padded = (width + 7) // 8 * 8
+    if padded == width:
+        return torch.empty((n_rows, width), device=device, dtype=dtype)
+    return torch.zeros((n_rows, padded), device=device, dtype=dtype)[:, :width]
+
+
+def rows16(t):
+    """A 2-D tensor as rows the kernels can address with 16-byte vector accesses: unit inner stride and a leading
+    dimension that is a multiple of 8 elements (already true for the padded buffers of alloc_rows); copies otherwise."""
+    if t.dim() == 2 and t.stride(1) == 1 and (t.stride(0) % 8 == 0 or t.shape[0] <= 1) and t.data_ptr() % 16 == 0:
+        return t
+    out = alloc_rows(t.shape[0], t.shape[1], t.dtype, t.device)
+    out.copy_(t)
+    return out
+
+
 def _rowmajor(t):
     assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view expected"
     return t.stride(0)
@@ -50,7 +70,7 @@ def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=N
     else:
         K, M = A.shape; N = B.shape[1]; assert B.shape[0] == K
     if out is None:
-        out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
+        out = alloc_rows(M, N, out_dtype or A.dtype, A.device)
         assert not accumulate and split_k == 1
     a = L.GemmArgs()
     a.dtype, a.layout = dt(A), layout
@@ -198,9 +218,9 @@ def scatter_rows(dout, idx, dx):
 def log_softmax_fwd(logits):
     _req_cuda(logits)
     N, V = logits.shape
-    lp = torch.empty((N, V), device=logits.device, dtype=torch.float32)
+    lp = alloc_rows(N, V, torch.float32, logits.device)
     lse = torch.empty(N, device=logits.device, dtype=torch.float32)
-    L.check(L.load().imt_log_softmax_fwd(dt(logits), _p(logits), _rowmajor(logits) if N else V, _p(lp), V, _p(lse), N, V,
+    L.check(L.load().imt_log_softmax_fwd(dt(logits), _p(logits), _rowmajor(logits) if N else V, _p(lp), lp.stride(0) if N else V, _p(lse), N, V,
                                          _stream()), "imt_log_softmax_fwd")
     return lp, lse
 
@@ -208,8 +228,10 @@ def log_softmax_fwd(logits):
 def log_softmax_bwd(dlp, lp, out_dtype):
     _req_cuda(dlp, lp)
     N, V = lp.shape
-    out = torch.empty((N, V), device=lp.device, dtype=out_dtype)
-    L.check(L.load().imt_log_softmax_bwd(_p(dlp), _rowmajor(dlp) if N else V, _p(lp), V, dt(out), _p(out), V, N, V, _stream()),
+    out = alloc_rows(N, V, out_dtype, lp.device)
+    lp, dlp = rows16(lp), rows16(dlp)
+    L.check(L.load().imt_log_softmax_bwd(_p(dlp), dlp.stride(0) if N else V, _p(lp), lp.stride(0) if N else V, dt(out), _p(out),
+                                         out.stride(0) if N else V, N, V, _stream()),
             "imt_log_softmax_bwd")
     return out
 
@@ -226,8 +248,8 @@ def smoothed_nll_fwd(lp, target, epsilon, ignore_index):
 def smoothed_nll_bwd(dloss, target, V, epsilon, ignore_index):
     _req_cuda(dloss, target)
     N = target.numel()
-    dlp = torch.empty((N, V), device=dloss.device, dtype=torch.float32)
-    L.check(L.load().imt_smoothed_nll_bwd(_p(dloss), _p(target), _p(dlp), V, N, V, epsilon, ignore_index, _stream()),
+    dlp = alloc_rows(N, V, torch.float32, dloss.device)
+    L.check(L.load().imt_smoothed_nll_bwd(_p(dloss), _p(target), _p(dlp), dlp.stride(0) if N else V, N, V, epsilon, ignore_index, _stream()),
             "imt_smoothed_nll_bwd")
     return dlp
 

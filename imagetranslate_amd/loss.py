@@ -13,7 +13,7 @@ from . import hip_ops as O
 class _SmoothedNLLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lp, target, epsilon, ignore_index):
-        lp = lp.float().contiguous()
+        lp = O.rows16(lp.float())
         target = target.to(lp.device).contiguous()
         ctx.save_for_backward(target)
         ctx.V, ctx.eps, ctx.ign = lp.shape[1], epsilon, ignore_index

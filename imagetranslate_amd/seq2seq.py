@@ -11,6 +11,7 @@ exactly as the reference.  Build extensions (keyword-only, documented deviations
     (``src/loss.py``) + ``.mean()`` without materialising the ``[N, V]`` log-prob matrix in fp32.
 """
 import copy
+import json
 import os
 import pickle
 import weakref
@@ -37,7 +38,7 @@ class _LogSoftmaxFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits):
-        lp, _ = O.log_softmax_fwd(logits.contiguous())
+        lp, _ = O.log_softmax_fwd(O.rows16(logits))
         ctx.save_for_backward(lp)
         ctx.in_dtype = logits.dtype
         return lp
@@ -45,7 +46,7 @@ class _LogSoftmaxFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlp):
         (lp,) = ctx.saved_tensors
-        return O.log_softmax_bwd(dlp.float().contiguous(), lp, ctx.in_dtype)
+        return O.log_softmax_bwd(O.rows16(dlp.float()), lp, ctx.in_dtype)
 
 
 class _SelectRowsFn(torch.autograd.Function):
@@ -353,6 +354,9 @@ class Seq2Seq(nn.Module):
                          self.intermediate_dim, self.tie_embed, self.resnet_depth, self.freeze_image), fp)
         torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()},
                    os.path.join(out_dir, "mt_model.state_dict"))
+        # build extension (the reference hard-codes 12 heads, src/seq2seq.py:37): remembered beside the reference files
+        with open(os.path.join(out_dir, "imt_config.json"), "w") as fp:
+            json.dump({"num_attention_heads": int(self.config.num_attention_heads)}, fp)
 
     @staticmethod
     def load(cls, out_dir: str, tok_dir: str, use_obj: bool = False, text_processor=None, **kw):
@@ -363,6 +367,10 @@ class Seq2Seq(nn.Module):
         with open(os.path.join(out_dir, "mt_config"), "rb") as fp:
             (lang_dec, use_proposals, enc_layer, dec_layer, embed_dim, intermediate_dim, tie_embed, resnet_depth,
              freeze_image) = pickle.load(fp)
+        extra = os.path.join(out_dir, "imt_config.json")
+        if "num_attention_heads" not in kw and os.path.exists(extra):
+            with open(extra, "r") as fp:
+                kw["num_attention_heads"] = int(json.load(fp)["num_attention_heads"])
         mt_model = cls(text_processor=text_processor, lang_dec=lang_dec, use_proposals=use_proposals, tie_embed=tie_embed,
                        enc_layer=enc_layer, dec_layer=dec_layer, embed_dim=embed_dim, intermediate_dim=intermediate_dim,
                        freeze_image=freeze_image, resnet_depth=resnet_depth, use_obj=use_obj, **kw)

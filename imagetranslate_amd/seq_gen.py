@@ -171,7 +171,7 @@ class BeamDecoder(nn.Module):
         inc = None
         if self.kv_cache:
             inc = _Incremental(lib, decoder, store, dtype, flat, encoder_states, enc_mask, B, beam, t_max, stream)
-        logits = torch.empty((B * beam, V), dtype=torch.float32, device=device)
+        logits = O.alloc_rows(B * beam, V, torch.float32, device)  # leading dimension padded to 8 for odd vocabularies
         hidden = torch.empty((B * beam, model.config.hidden_size), dtype=dtype, device=device)
 
         n_cols = 1
@@ -203,7 +203,7 @@ class BeamDecoder(nn.Module):
 
             a = L.BeamArgs()
             a.B, a.beam, a.rep, a.V, a.step, a.t_max = B, beam, rep, V, i, t_max
-            a.logits, a.ld = logits.data_ptr(), V
+            a.logits, a.ld = logits.data_ptr(), logits.stride(0)
             a.scores_in, a.sizes_in, a.eos_in = st.scores[cur].data_ptr(), st.sizes[cur].data_ptr(), st.eos[cur].data_ptr()
             a.max_lens, a.hist_in = max_lens.data_ptr(), st.hist[cur].data_ptr()
             a.len_penalty_ratio, a.pad_idx, a.eos = float(self.len_penalty_ratio), int(pad_idx), int(eos)

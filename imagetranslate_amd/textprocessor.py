@@ -52,9 +52,14 @@ class TextProcessor:
         self.languages: Dict[str, int] = {}
         self.tokenizer = None
         if tok_model_path is not None:
-            from tokenizers import SentencePieceBPETokenizer
-            self.tokenizer = SentencePieceBPETokenizer(os.path.join(tok_model_path, "vocab.json"),
-                                                       os.path.join(tok_model_path, "merges.txt"))
+            full = os.path.join(tok_model_path, "tokenizer.json")
+            if os.path.exists(full):  # written by train_tokenizer below: the complete tokenizer in one file
+                from tokenizers import Tokenizer
+                self.tokenizer = Tokenizer.from_file(full)
+            else:  # a directory written by the reference (vocab.json + merges.txt)
+                from tokenizers import SentencePieceBPETokenizer
+                self.tokenizer = SentencePieceBPETokenizer(os.path.join(tok_model_path, "vocab.json"),
+                                                           os.path.join(tok_model_path, "merges.txt"))
             with open(os.path.join(tok_model_path, "langs"), "rb") as fp:
                 self.languages = pickle.load(fp)
         self._init_properties(self.languages)
@@ -70,9 +75,16 @@ class TextProcessor:
         from tokenizers import SentencePieceBPETokenizer
         self.tokenizer = SentencePieceBPETokenizer()
         self._init_properties(languages)
-        self.tokenizer.train(files=paths, vocab_size=vocab_size, min_frequency=5, special_tokens=self.special_tokens)
+        def lines():
+            for path in paths:
+                with open(path, "r") as fp:
+                    for line in fp:
+                        if line.strip():
+                            yield line.strip()  # no trailing newline: it would be learnt as a symbol
+        self.tokenizer.train_from_iterator(lines(), vocab_size=vocab_size, min_frequency=5, special_tokens=self.special_tokens)
         os.makedirs(to_save_dir, exist_ok=True)
-        self.tokenizer.save_model(to_save_dir)  # tokenizers >= 0.10: save_model writes vocab.json + merges.txt
+        self.tokenizer.save_model(to_save_dir)  # vocab.json + merges.txt (the reference's layout)
+        self.tokenizer.save(os.path.join(to_save_dir, "tokenizer.json"))
         with open(os.path.join(to_save_dir, "langs"), "wb") as fp:
             pickle.dump(self.languages, fp)
 
@@ -95,6 +107,19 @@ class TextProcessor:
 
     def lang_id(self, tok) -> int:
         return self.languages.get(tok, 0)
+
+    def tokenize_one_sentence_with_langid(self, line, lang_id):
+        """ids of ``line`` framed as [lang_id] ... </s> (src/textprocessor.py:74-76), truncated to 512."""
+        return ([lang_id] + self.tokenizer.encode(line).ids + [self.token_id(self.sep_token)])[:512]
+
+    def tokenize(self, lines):
+        rows = [ln.strip() for ln in lines.strip().split("\n") if ln.strip()]
+        return [enc.ids for enc in self.tokenizer.encode_batch(rows)]
+
+    def decode(self, ids) -> str:
+        """ids -> text without the special tokens (language tag, </s>, padding)."""
+        specials = {self.token_id(t) for t in self.special_tokens}
+        return self.tokenizer.decode([int(i) for i in ids if int(i) not in specials], skip_special_tokens=True)
 
     def tokenize_one_sentence(self, line):
         """'<lang> words ... </s>' -> ids (language tag first, end-of-sentence last), truncated to 512."""

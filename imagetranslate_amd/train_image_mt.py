@@ -1,0 +1,191 @@
+"""Training entry point for the text path -- thin counterpart of src/train_image_mt.py (``ImageMTTrainer``
+``:44-333`` and ``train`` ``:394-560``): supervised MT batches and/or MASS batches, label-smoothed loss, gradient
+clipping + inverse-sqrt Adam, dev-set loss, best-checkpoint saving, one process per GPU under torch.distributed.
+Everything the reference trainer does around the step that needs absent packages (apex, sacrebleu, torchvision
+image pipeline, back-translation scheduling) is left out; the model step itself is the HIP path."""
+import datetime
+import math
+import os
+import random
+from optparse import OptionParser
+
+import torch
+
+from . import dataset
+from .image_model import ImageMassSeq2Seq
+from .parallel import GradSync, train_step
+from .textprocessor import TextProcessor
+from .utils import build_optimizer, mass_mask, mass_unmask
+
+
+class ImageMTTrainer:
+    def __init__(self, model, mask_prob: float = 0.3, clip: float = 1.0, optimizer=None, rank: int = 0, world_size: int = 1):
+        self.model = model
+        self.clip = clip
+        self.optimizer = optimizer
+        self.mask_prob = mask_prob
+        self.rank, self.world_size = rank, world_size
+        self.sync = GradSync(model) if world_size > 1 else None
+        self.best_loss = float("inf")
+
+    # one MT batch (src/train_image_mt.py:239-295)
+    def mt_step(self, batch):
+        batch = {k: (v[0] if isinstance(v, list) else v) for k, v in batch.items()}
+        loss, ntokens = train_step(self.model, self.optimizer, batch, sync=self.sync, clip=self.clip)
+        return float(loss.detach()), int(ntokens)
+
+    # one MASS batch (src/train_image_mt.py:186-236): mask a span, recover it with its original positions
+    def mass_step(self, batch):
+        tp = self.model.text_processor
+        src = batch["src_texts"].clone()
+        masked = mass_mask(self.mask_prob, batch["pad_idx"], src, tp)
+        if self.sync is not None:
+            self.sync.begin_step()
+        loss, ntokens = self.model.loss_fused(src_inputs=masked["src_text"], tgt_inputs=masked["to_recover"],
+                                              src_langs=batch["langs"], pad_idx=tp.pad_token_id(),
+                                              tgt_positions=masked["positions"])
+        loss.backward()
+        scale = self.sync.finish() if self.sync is not None else 1.0
+        self.optimizer.step(max_grad_norm=self.clip, grad_scale=scale, zero_grad=True)
+        mass_unmask(masked["src_text"], masked["src_mask"], masked["mask_idx"])
+        return float(loss.detach()), int(ntokens)
+
+    @torch.no_grad()
+    def dev_loss(self, dev_data):
+        self.model.eval()
+        total, count = 0.0, 0
+        for batch in dev_data:
+            loss, n = self.model.loss_fused(src_inputs=batch["src_texts"], tgt_inputs=batch["dst_texts"],
+                                            src_langs=batch["src_langs"], tgt_langs=batch["dst_langs"])
+            total += float(loss) * int(n)
+            count += int(n)
+        self.model.train()
+        return total / max(count, 1)
+
+    def train_epoch(self, mt_data=None, mass_data=None, dev_data=None, step: int = 0, max_step: int = 10 ** 9,
+                    save_path: str = None, log_every: int = 50, eval_every: int = 500):
+        order = [("mt", i) for i in range(len(mt_data or []))] + [("mass", i) for i in range(len(mass_data or []))]
+        random.shuffle(order)
+        order = order[self.rank::self.world_size]  # DistributedSampler over pre-built batches (:586-589)
+        tokens, total_loss, t0 = 0, 0.0, datetime.datetime.now()
+        for kind, i in order:
+            if step >= max_step:
+                break
+            try:
+                loss, n = self.mt_step(mt_data[i]) if kind == "mt" else self.mass_step(mass_data[i])
+            except RuntimeError as err:  # the reference trainer skips a failing batch and goes on (:327-333)
+                print("skipping batch:", repr(err))
+                self.optimizer.zero_grad()
+                continue
+            step += 1
+            tokens += n
+            total_loss += loss * n
+            if step % log_every == 0 and self.rank == 0:
+                secs = (datetime.datetime.now() - t0).total_seconds()
+                print(datetime.datetime.now(), "step", step, "loss %.4f" % (total_loss / max(tokens, 1)), "tokens/s %.0f" % (tokens / max(secs, 1e-9)),
+                      "lr %.2e" % self.optimizer.param_groups[0]["lr"], flush=True)
+                tokens, total_loss, t0 = 0, 0.0, datetime.datetime.now()
+            if dev_data is not None and step % eval_every == 0:
+                self.validate_and_save(dev_data, save_path)
+        return step
+
+    def validate_and_save(self, dev_data, save_path):
+        dl = self.dev_loss(dev_data)
+        if self.rank == 0:
+            print(datetime.datetime.now(), "dev loss %.4f (best %.4f)" % (dl, self.best_loss), flush=True)
+            if dl < self.best_loss and save_path:
+                self.model.save(save_path)
+        self.best_loss = min(self.best_loss, dl)
+        return dl
+
+
+def get_option_parser():
+    parser = OptionParser()
+    parser.add_option("--train", dest="mt_train_path", default=None, help="comma-separated MT example files")
+    parser.add_option("--dev", dest="mt_dev_path", default=None)
+    parser.add_option("--mass_train", dest="mass_train_path", default=None, help="comma-separated monolingual example files")
+    parser.add_option("--tok", dest="tokenizer_path")
+    parser.add_option("--model", dest="model_path", help="directory for the best checkpoint")
+    parser.add_option("--pretrained", dest="pretrained_path", default=None)
+    parser.add_option("--epoch", dest="num_epochs", type="int", default=100)
+    parser.add_option("--step", dest="step", type="int", default=500000)
+    parser.add_option("--batch", dest="batch", type="int", default=6000, help="(S+T)*n budget per batch")
+    parser.add_option("--capacity", dest="total_capacity", type="int", default=600)
+    parser.add_option("--lr", dest="learning_rate", type="float", default=1e-4)
+    parser.add_option("--warmup", dest="warmup", type="int", default=12500)
+    parser.add_option("--clip", dest="clip", type="float", default=1.0)
+    parser.add_option("--mask", dest="mask_prob", type="float", default=0.3)
+    parser.add_option("--embed", dest="embed_dim", type="int", default=768)
+    parser.add_option("--intermediate", dest="intermediate_layer_dim", type="int", default=3072)
+    parser.add_option("--enc", dest="encoder_layer", type="int", default=6)
+    parser.add_option("--dec", dest="decoder_layer", type="int", default=6)
+    parser.add_option("--heads", dest="heads", type="int", default=12)
+    parser.add_option("--max_seq_len", dest="max_seq_len", type="int", default=175)
+    parser.add_option("--tie", action="store_true", dest="tie_embed", default=False)
+    parser.add_option("--ldec", action="store_true", dest="lang_decoder", default=False)
+    parser.add_option("--fp32", action="store_true", dest="fp32", default=False, help="fp32 compute (default bf16)")
+    parser.add_option("--seed", dest="seed", type="int", default=1234)
+    parser.add_option("--eval-steps", dest="eval_steps", type="int", default=500)
+    parser.add_option("--log-steps", dest="log_steps", type="int", default=50)
+    return parser
+
+
+def train(options):
+    rank, world = 0, 1
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+        rank, world = dist.get_rank(), dist.get_world_size()
+    random.seed(options.seed)
+    torch.manual_seed(options.seed)
+    tp = TextProcessor(options.tokenizer_path)
+    if options.pretrained_path:
+        model = ImageMassSeq2Seq.load(ImageMassSeq2Seq, options.pretrained_path, tok_dir=options.tokenizer_path)
+    else:
+        model = ImageMassSeq2Seq(text_processor=tp, lang_dec=options.lang_decoder, tie_embed=options.tie_embed,
+                                 enc_layer=options.encoder_layer, dec_layer=options.decoder_layer, embed_dim=options.embed_dim,
+                                 intermediate_dim=options.intermediate_layer_dim, num_attention_heads=options.heads)
+    model.set_compute_dtype(torch.float32 if options.fp32 else torch.bfloat16)
+    model = model.cuda().train()
+    if world > 1:
+        import torch.distributed as dist
+        from .param_store import store_of
+        dist.broadcast(store_of(model).ensure().flat, src=0)
+    optimizer = build_optimizer(model, options.learning_rate, options.warmup)
+    trainer = ImageMTTrainer(model, mask_prob=options.mask_prob, clip=options.clip, optimizer=optimizer, rank=rank, world_size=world)
+    pad = tp.pad_token_id()
+    mk = lambda cls, path, **kw: cls(max_batch_capacity=options.total_capacity, max_batch=options.batch, pad_idx=pad,
+                                     max_seq_len=options.max_seq_len, ngpu=1, **kw, **path)
+    mt_train, mass_train, mt_dev = [], [], None
+    for pth in (options.mt_train_path or "").split(","):
+        if pth.strip():
+            mt_train += mk(dataset.MTDataset, dict(batch_pickle_dir=pth.strip())).batches
+    for pth in (options.mass_train_path or "").split(","):
+        if pth.strip():
+            mass_train += mk(dataset.MassDataset, dict(batch_pickle_dir=pth.strip())).batches
+    if options.mt_dev_path:
+        mt_dev = mk(dataset.MTDataset, dict(batch_pickle_dir=options.mt_dev_path)).batches
+    if rank == 0:
+        print("MT batches", len(mt_train), "MASS batches", len(mass_train), "dev batches", len(mt_dev or []), flush=True)
+    step = 0
+    for epoch in range(options.num_epochs):
+        if step >= options.step:
+            break
+        step = trainer.train_epoch(mt_data=mt_train, mass_data=mass_train, dev_data=mt_dev, step=step, max_step=options.step,
+                                   save_path=options.model_path, log_every=options.log_steps, eval_every=options.eval_steps)
+    if mt_dev is not None:
+        trainer.validate_and_save(mt_dev, options.model_path)
+    elif rank == 0 and options.model_path:
+        model.save(options.model_path)
+    return trainer
+
+
+def main(argv=None):
+    options, _ = get_option_parser().parse_args(argv)
+    train(options)
+
+
+if __name__ == "__main__":
+    main()

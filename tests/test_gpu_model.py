@@ -154,6 +154,55 @@ def test_fused_loss_equals_api_path_and_train_steps(cuda):
     assert l2 == pytest.approx(fx["step_losses"], rel=2e-4)
 
 
+@pytest.mark.parametrize("V", [193, 997, 1002])
+def test_vocabulary_size_not_a_multiple_of_eight(cuda, V):
+    """Real tokenizers give arbitrary vocabulary sizes: logits / log-prob rows are then padded to 16-byte multiples
+    internally (strided views outside); forward, API loss path, fused loss path and gradients against the oracle,
+    fp32 and bf16, plus beam search on such a model."""
+    ref, ours = _pair(V=V)
+    b = _toy_batch(V=V)
+    args = (b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
+    lp_ref = ref(*args, log_softmax=True)
+    lp = ours(*args, log_softmax=True)
+    assert lp.shape == lp_ref.shape == (int(b["dst_pad_mask"][:, 1:].sum()), V)
+    assert_close(lp, lp_ref, 1e-4, "log-probs")
+    assert torch.equal(lp.argmax(-1).cpu(), lp_ref.argmax(-1))
+    targets = b["dst_texts"][:, 1:].contiguous().view(-1)[b["dst_pad_mask"][:, 1:].contiguous().view(-1)]
+    loss_ref = R.SmoothedNLLLoss(ignore_index=0)(lp_ref, targets).mean()
+    loss_ref.backward()
+    from imagetranslate_amd.loss import SmoothedNLLLoss
+    loss = SmoothedNLLLoss(ignore_index=0)(lp, targets.cuda()).mean()
+    loss.backward()
+    assert float(loss) == pytest.approx(float(loss_ref), rel=1e-5)
+    keys = ["output_layer.1.layer.weight", "output_layer.1.layer.bias", "decoder.decoder.layer.1.output.dense.weight",
+            "encoder.embeddings.word_embeddings.weight"]
+    g_api = {k: _grad_of(ours, k).clone() for k in keys}
+    for k in keys:
+        assert_close(g_api[k], _grad_of(ref, k), 2e-4, "API-path grad " + k)
+    ours.zero_grad()
+    fused, ntok = ours.loss_fused(*args)
+    fused.backward()
+    assert ntok == lp.shape[0] and float(fused) == pytest.approx(float(loss_ref), rel=1e-5)
+    for k in keys:
+        assert_close(_grad_of(ours, k), _grad_of(ref, k), 2e-4, "fused-path grad " + k)
+    ours.zero_grad()
+    ours.set_compute_dtype(torch.bfloat16)
+    fused16, _ = ours.loss_fused(*args)
+    fused16.backward()
+    assert float(fused16) == pytest.approx(float(loss_ref), rel=2e-2)
+    assert_close(_grad_of(ours, keys[0]), _grad_of(ref, keys[0]), 6e-2, "bf16 fused grad")
+    # beam search with the padded logits rows
+    from imagetranslate_amd.seq_gen import BeamDecoder
+    from oracle.seq_gen import BeamDecoder as OracleBeam
+    ours.set_compute_dtype(torch.float32)
+    n = 4
+    kw = dict(src_inputs=b["src_texts"][:n], src_sizes=b["src_pad_mask"][:n].sum(1), first_tokens=torch.full((n,), 6),
+              src_mask=b["src_pad_mask"][:n], src_langs=b["src_langs"][:n], tgt_langs=b["dst_langs"][:n], pad_idx=0, max_len=9)
+    exp = OracleBeam(ref, beam_width=3)(**kw)
+    got = BeamDecoder(ours.eval(), beam_width=3)(**kw)
+    assert [g.tolist() for g in got] == [e.tolist() for e in exp]
+
+
 def test_bf16_mode_tracks_fp32(cuda):
     ref, ours = _pair()
     ours.set_compute_dtype(torch.bfloat16)
