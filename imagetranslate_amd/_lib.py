@@ -136,6 +136,15 @@ class BeamArgs(Structure):
     ]
 
 
+class MassArgs(Structure):
+    _fields_ = [
+        ("n_rows", c_int32), ("width", c_int32), ("recover_width", c_int32), ("n_special", c_int32), ("vocab", c_int32),
+        ("mask_prob", c_float), ("seed", c_uint64), ("mask_id", c_int64), ("pad_id", c_int64),
+        ("src_text", c_void_p), ("pad_indices", c_void_p), ("row_offsets", c_void_p), ("src_mask", c_void_p),
+        ("to_recover", c_void_p), ("positions", c_void_p), ("targets", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/imt_hip.h declares (tests/test_cabi.py checks)
 _P = c_void_p
 SIGNATURES = {
@@ -175,6 +184,8 @@ SIGNATURES = {
     "imt_decode_begin": (c_int, [POINTER(StackDesc), _P, c_int, c_int, _P, _P]),
     "imt_decode_step": (c_int, [POINTER(StackDesc), POINTER(DecodeIO), _P, c_int64, _P]),
     "imt_beam_step": (c_int, [POINTER(BeamArgs), _P]),
+    "imt_mass_mask": (c_int, [POINTER(MassArgs), _P]),
+    "imt_mass_unmask": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
 }
 
 _lib = None

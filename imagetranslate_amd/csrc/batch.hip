@@ -1,0 +1,112 @@
+// On-device batch construction for MASS (src/utils.py:41-82): span selection, the shifted
+// decoder input with its original positions, compaction of the hidden tokens and the 80/10/10 replacement -- integer
+// work, one workgroup per sentence, so a MASS step needs no per-token host loop and no host->device copy of masks.
+// Randomness is counter-based (mix32 of (seed, stream, index)), restated bit for bit by oracle/batch_oracle.py.
+#include "common.hpp"
+
+namespace {
+
+IMT_DEVICE float mass_uniform(uint64_t seed, uint32_t stream, uint32_t index) {  // [0, 1) with 24 bits
+  uint32_t h = mix32(index ^ (uint32_t)seed);
+  h = mix32(h + stream * 0x9e3779b9U + (uint32_t)(seed >> 32));
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void mass_mask_kernel(imt_mass_args a) {
+  __shared__ int s_first, s_len;
+  const int row = blockIdx.x;
+  int64_t* text = a.src_text + (int64_t)row * a.width;
+  if (threadIdx.x == 0) {
+    const int64_t pad = a.pad_indices[row];
+    const int span_len = (int)(pad / 2);
+    // float32 with TWO roundings like the reference's tensor expression pad - (1-p)*pad: no fused multiply-add (HIP's
+    // __fmul_rn / __fsub_rn are plain operators and would be contracted), e.g. pad = 50: 50 - 35.0 = 15, fma gives 15.0000006
+    float bound;
+    {
+#pragma clang fp contract(off)
+      const float prod = (1.0f - a.mask_prob) * (float)pad;
+      bound = (float)pad - prod;
+    }
+    const int hint = (int)ceilf(bound);
+    const float u0 = mass_uniform(a.seed, 0u, (uint32_t)row);
+    int first;
+    if (u0 > 0.8f) first = 1;
+    else if (u0 > 0.6f) first = hint;
+    else if (hint >= 2) {
+      first = 2 + (int)(mass_uniform(a.seed, 1u, (uint32_t)row) * (float)(hint - 1));
+      if (first > hint) first = hint;
+    } else first = 2;
+    s_first = first; s_len = span_len;
+  }
+  __syncthreads();
+  const int first = s_first, len = s_len;
+  const int last = min(first + len, a.width);  // python slice semantics
+  const int64_t off = a.row_offsets[row];
+  // span mask
+  for (int c = threadIdx.x; c < a.width; c += 256) a.src_mask[(int64_t)row * a.width + c] = (c >= first && c < last) ? 1 : 0;
+  // decoder input = tokens first-1 .. last-1 with their original positions (read BEFORE the replacement below)
+  for (int k = threadIdx.x; k < a.recover_width; k += 256) {
+    const int c = first - 1 + k;
+    const bool in = (c >= 0 && c < last && k <= last - first);
+    a.to_recover[(int64_t)row * a.recover_width + k] = in ? text[c] : a.pad_id;
+    a.positions[(int64_t)row * a.recover_width + k] = in ? (int64_t)c : (int64_t)(a.width - 1);
+  }
+  __syncthreads();
+  // hidden tokens: compacted originals (== prediction targets) and the 80/10/10 replacement, in place
+  for (int k = threadIdx.x; k < last - first; k += 256) {
+    const int c = first + k;
+    const int64_t orig = text[c];
+    a.targets[off + k] = orig;
+    const uint32_t idx = (uint32_t)(row * a.width + c);
+    const float u = mass_uniform(a.seed, 2u, idx);
+    int64_t repl = orig;
+    if (u < 0.8f) repl = a.mask_id;
+    else if (u < 0.9f) {
+      const int span = a.vocab - a.n_special;
+      int r = (int)(mass_uniform(a.seed, 3u, idx) * (float)span);
+      if (r >= span) r = span - 1;
+      repl = a.n_special + r;
+    }
+    text[c] = repl;
+  }
+}
+
+__global__ __launch_bounds__(256) void mass_unmask_kernel(int64_t* text, const uint8_t* mask, const int64_t* originals,
+                                                          const int64_t* row_offsets, int width) {
+  __shared__ int s_first;
+  const int row = blockIdx.x;
+  if (threadIdx.x == 0) s_first = width;
+  __syncthreads();
+  int mine = width;
+  for (int c = threadIdx.x; c < width; c += 256)
+    if (mask[(int64_t)row * width + c]) { mine = c; break; }
+  atomicMin(&s_first, mine);
+  __syncthreads();
+  const int first = s_first;
+  for (int c = first + threadIdx.x; c < width; c += 256)
+    if (mask[(int64_t)row * width + c]) text[(int64_t)row * width + c] = originals[row_offsets[row] + (c - first)];
+}
+
+}  // namespace
+
+extern "C" int imt_mass_mask(const imt_mass_args* a, void* stream) {
+  IMT_CHECK_ARG(a, "mass_mask: null args");
+  IMT_CHECK_ARG(a->n_rows > 0 && a->width > 1 && a->recover_width > 0, "mass_mask: bad sizes");
+  IMT_CHECK_ARG(a->mask_prob > 0.f && a->mask_prob < 1.f, "mass_mask: mask_prob must be in (0, 1)");
+  IMT_CHECK_ARG(a->vocab > a->n_special && a->n_special >= 0, "mass_mask: vocabulary smaller than the special-token block");
+  IMT_CHECK_ARG(a->src_text && a->pad_indices && a->row_offsets && a->src_mask && a->to_recover && a->positions && a->targets,
+                "mass_mask: null tensor");
+  hipStream_t st = (hipStream_t)stream;
+  ImtProfScope prof("mass_mask", 0, (double)a->n_rows * a->width * 17, st);
+  hipLaunchKernelGGL(mass_mask_kernel, dim3(a->n_rows), dim3(256), 0, st, *a);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+extern "C" int imt_mass_unmask(int64_t* src_text, const uint8_t* src_mask, const int64_t* originals, const int64_t* row_offsets,
+                               int n_rows, int width, void* stream) {
+  IMT_CHECK_ARG(src_text && src_mask && originals && row_offsets && n_rows > 0 && width > 0, "mass_unmask: bad args");
+  hipLaunchKernelGGL(mass_unmask_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, src_text, src_mask, originals, row_offsets, width);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}

@@ -15,7 +15,7 @@ from . import dataset
 from .image_model import ImageMassSeq2Seq
 from .parallel import GradSync, train_step
 from .textprocessor import TextProcessor
-from .utils import build_optimizer, mass_mask, mass_unmask
+from .utils import build_optimizer, mass_mask_device
 
 
 class ImageMTTrainer:
@@ -37,8 +37,8 @@ class ImageMTTrainer:
     # one MASS batch (src/train_image_mt.py:186-236): mask a span, recover it with its original positions
     def mass_step(self, batch):
         tp = self.model.text_processor
-        src = batch["src_texts"].clone()
-        masked = mass_mask(self.mask_prob, batch["pad_idx"], src, tp)
+        src = batch["src_texts"].cuda()  # a device copy: the dataset's tensor is never modified, no unmask needed
+        masked = mass_mask_device(self.mask_prob, batch["pad_idx"], src, tp, seed=random.getrandbits(62))
         if self.sync is not None:
             self.sync.begin_step()
         loss, ntokens = self.model.loss_fused(src_inputs=masked["src_text"], tgt_inputs=masked["to_recover"],
@@ -47,7 +47,6 @@ class ImageMTTrainer:
         loss.backward()
         scale = self.sync.finish() if self.sync is not None else 1.0
         self.optimizer.step(max_grad_norm=self.clip, grad_scale=scale, zero_grad=True)
-        mass_unmask(masked["src_text"], masked["src_mask"], masked["mask_idx"])
         return float(loss.detach()), int(ntokens)
 
     @torch.no_grad()

@@ -193,3 +193,53 @@ def mass_mask(mask_prob, pad_indices, src_text, text_processor) -> Dict:
 def mass_unmask(src_text, src_mask, masked_ids):
     """Undo mass_mask in place after the step (src/utils.py:81-82)."""
     src_text[src_mask] = masked_ids
+
+
+# ----------------------------------------------------------------------------------------- device batch construction
+def mass_mask_device(mask_prob, pad_indices, src_text, text_processor, seed: int) -> Dict:
+    """mass_mask on the GPU (imt_mass_mask): same outputs and the same in-place semantics as ``mass_mask`` above, all
+    tensors on the device of ``src_text``.  Span starts and the 80/10/10 replacement use the kernel's counter-based
+    generator keyed by ``seed`` instead of Python's ``random`` (same procedure, different stream); only the sizes that
+    follow from ``pad_indices`` are computed on the host."""
+    import ctypes
+    from . import _lib as L
+    if not src_text.is_cuda:
+        raise L.ImtError("mass_mask_device needs src_text on the GPU (use mass_mask on the host)")
+    assert 0 < mask_prob < 1
+    n_rows, width = src_text.shape
+    span_len = (pad_indices.cpu().to(torch.int64) // 2)
+    offsets = torch.cumsum(span_len, 0) - span_len
+    total, recover_width = int(span_len.sum()), int(span_len.max()) + 1
+    dev = src_text.device
+    src_text = src_text.contiguous()
+    out = {"src_mask": torch.empty((n_rows, width), dtype=torch.uint8, device=dev),
+           "to_recover": torch.empty((n_rows, recover_width), dtype=torch.int64, device=dev),
+           "positions": torch.empty((n_rows, recover_width), dtype=torch.int64, device=dev),
+           "targets": torch.empty(total, dtype=torch.int64, device=dev)}
+    pad_dev, off_dev = pad_indices.to(dev, torch.int64).contiguous(), offsets.to(dev)
+    a = L.MassArgs()
+    a.n_rows, a.width, a.recover_width = n_rows, width, recover_width
+    a.n_special, a.vocab = len(text_processor.special_tokens), text_processor.vocab_size()
+    a.mask_prob, a.seed = float(mask_prob), int(seed)
+    a.mask_id, a.pad_id = text_processor.mask_token_id(), text_processor.pad_token_id()
+    a.src_text, a.pad_indices, a.row_offsets = src_text.data_ptr(), pad_dev.data_ptr(), off_dev.data_ptr()
+    a.src_mask, a.to_recover = out["src_mask"].data_ptr(), out["to_recover"].data_ptr()
+    a.positions, a.targets = out["positions"].data_ptr(), out["targets"].data_ptr()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(L.load().imt_mass_mask(ctypes.byref(a), st), "imt_mass_mask")
+    out["src_mask"] = out["src_mask"].bool()
+    out["src_text"] = src_text
+    out["mask_idx"] = out["targets"]
+    out["_row_offsets"] = off_dev
+    return out
+
+
+def mass_unmask_device(masked: Dict):
+    """Restore the source ids hidden by mass_mask_device (in place)."""
+    import ctypes
+    from . import _lib as L
+    t, m = masked["src_text"], masked["src_mask"].to(torch.uint8).contiguous()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(L.load().imt_mass_unmask(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(m.data_ptr()),
+                                     ctypes.c_void_p(masked["mask_idx"].data_ptr()), ctypes.c_void_p(masked["_row_offsets"].data_ptr()),
+                                     t.shape[0], t.shape[1], st), "imt_mass_unmask")

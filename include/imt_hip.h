@@ -363,6 +363,35 @@ typedef struct imt_beam_args {
 } imt_beam_args;
 int imt_beam_step(const imt_beam_args* a, void* stream);
 
+/* ------------------------------------------------------------------ MASS batch construction on device
+ * mass_mask / mass_unmask of src/utils.py:41-82.  Per sentence (row): a contiguous span of int(pad_index/2) tokens
+ * starting at `first` is hidden from the encoder, where first = 1 (20%), the bound ceil(pad - (1-p)*pad) (20%) or
+ * uniform in [2, bound] (60%) (src/utils.py:52-60); the decoder input `to_recover` is the span shifted right by one
+ * with its ORIGINAL positions; hidden tokens become <mask> (80%), a random non-special id (10%) or stay (10%).
+ * The random draws are counter-based on (seed, stream, index) -- NOT Python's generator: the same statistical
+ * procedure, reproducible on device.  Sizes that depend only on pad_indices are computed by the caller:
+ *   row_offsets[r] = sum_{q<r} int(pad_indices[q]/2)   (exclusive prefix sum; total = number of targets)
+ *   recover_width  = max_r int(pad_indices[r]/2) + 1
+ * src_text is modified in place (like the reference); imt_mass_unmask restores it from `targets`.
+ */
+typedef struct imt_mass_args {
+  int32_t n_rows, width, recover_width;
+  int32_t n_special, vocab;  /* replacement ids are drawn from [n_special, vocab) */
+  float mask_prob;
+  uint64_t seed;
+  int64_t mask_id, pad_id;
+  int64_t* src_text;            /* [n_rows, width] in/out */
+  const int64_t* pad_indices;   /* [n_rows] index of the first pad token (width-1 if none) */
+  const int64_t* row_offsets;   /* [n_rows] */
+  uint8_t* src_mask;            /* [n_rows, width] out: 1 on hidden positions */
+  int64_t* to_recover;          /* [n_rows, recover_width] out, padded with pad_id */
+  int64_t* positions;           /* [n_rows, recover_width] out, padded with width-1 */
+  int64_t* targets;             /* [total] out: hidden tokens in row-major order (== the reference's mask_idx) */
+} imt_mass_args;
+int imt_mass_mask(const imt_mass_args* a, void* stream);
+int imt_mass_unmask(int64_t* src_text, const uint8_t* src_mask, const int64_t* originals, const int64_t* row_offsets,
+                    int n_rows, int width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

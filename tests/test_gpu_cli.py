@@ -66,3 +66,34 @@ def test_tokenizer_batches_training_and_translation(cuda, tmp_path, capsys):
                     "--tok", tok, "--model", model_dir, "--beam", "2", "--fp32"])
     with open(os.path.join(d, "dev.out")) as fp:
         assert len(fp.read().strip().split("\n")) == 100
+
+
+def test_trainer_mass_steps_on_device_batches(cuda):
+    """MASS objective through the trainer: MassDataset batches -> imt_mass_mask on the device -> decoder with the
+    original positions -> fused loss; the loss falls on a tiny memorisable corpus."""
+    from imagetranslate_amd.dataset import MassDataset
+    from imagetranslate_amd.image_model import ImageMassSeq2Seq
+    from imagetranslate_amd.textprocessor import SyntheticTextProcessor
+    from imagetranslate_amd.train_image_mt import ImageMTTrainer
+    from imagetranslate_amd.utils import build_optimizer
+    rnd = random.Random(2)
+    torch.manual_seed(2)
+    random.seed(2)
+    tp = SyntheticTextProcessor(300)
+    sents = [[5] + [rnd.randint(7, 60) for _ in range(rnd.randint(8, 20))] + [4] for _ in range(48)]
+    sents.sort(key=len)
+    data = MassDataset(None, max_batch_capacity=50, max_batch=700, pad_idx=0, max_seq_len=64, example_list=[[(s, 0) for s in sents]])
+    assert len(data) >= 2 and all(b["src_texts"].size(0) >= 1 for b in data.batches)
+    model = ImageMassSeq2Seq(tp, lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512,
+                             num_attention_heads=4).cuda().train()
+    trainer = ImageMTTrainer(model, mask_prob=0.3, optimizer=build_optimizer(model, 2e-3, 20))
+    losses = []
+    for epoch in range(25):
+        for b in data.batches:
+            before = b["src_texts"].clone()
+            loss, n = trainer.mass_step(b)
+            assert torch.equal(b["src_texts"], before), "the dataset's tensors are not modified"
+            assert n == int((b["pad_idx"] // 2).sum())
+            losses.append(loss)
+    k = len(data)
+    assert sum(losses[-k:]) / k < 0.75 * sum(losses[:k]) / k, (losses[:k], losses[-k:])
