@@ -287,8 +287,16 @@ class Seq2Seq(nn.Module):
         return self.lexical_layer_norm(combined).to(dt)
 
     # shared tail of every forward variant: decoder -> non-pad row select -> vocabulary projection
+    @staticmethod
+    def _selection(tgt_inputs, tgt_mask):
+        """(row indices, targets) of the non-pad target positions (src/seq2seq.py:175-177, train_image_mt.py:253-256).
+        The row count is data dependent, so this is the step's ONE host synchronisation; the fast path calls it before
+        anything is enqueued so that it waits on nothing and the rest of the step is launched without bubbles."""
+        idx = torch.nonzero(tgt_mask[:, 1:].reshape(-1), as_tuple=False).view(-1)
+        return idx.to(torch.int32), tgt_inputs[:, 1:].reshape(-1)[idx]
+
     def _decode(self, encoder_states, enc_mask, tgt_inputs, tgt_mask, tgt_langs_t, batch_lang, position_ids=None,
-                proposals=None, pad_idx=0):
+                proposals=None, pad_idx=0, sel_idx=None):
         decoder = self.decoder if not self.lang_dec else self.decoder[batch_lang]
         decoder_output = decoder(encoder_states=encoder_states, input_ids=tgt_inputs[:, :-1],
                                  encoder_attention_mask=enc_mask, tgt_query_mask=tgt_mask[:, :-1],
@@ -296,8 +304,9 @@ class Seq2Seq(nn.Module):
         if self.use_proposals:
             decoder_output = self.attend_proposal(decoder_output, proposals, pad_idx)
         flat = decoder_output.reshape(-1, decoder_output.size(-1))
-        idx = torch.nonzero(tgt_mask[:, 1:].reshape(-1), as_tuple=False).view(-1).to(torch.int32)
-        return _SelectRowsFn.apply(flat, idx)
+        if sel_idx is None:
+            sel_idx = self._selection(tgt_inputs, tgt_mask)[0]
+        return _SelectRowsFn.apply(flat, sel_idx)
 
     def _project(self, rows, batch_lang, log_softmax):
         output_layer = self.output_layer if (not self.lang_dec) and self.tie_embed else self.output_layer[batch_lang]
@@ -334,13 +343,15 @@ class Seq2Seq(nn.Module):
         tgt_langs_t = tgt_langs.unsqueeze(-1).expand(-1, tgt_inputs.size(-1)).to(device)
         src_inputs, tgt_inputs = src_inputs.to(device), tgt_inputs.to(device)
         src_mask, tgt_mask = src_mask.to(device), tgt_mask.to(device)
+        sel_idx, targets = self._selection(tgt_inputs, tgt_mask)
         encoder_states = self.encode(src_inputs, src_mask, src_langs_t)[0]
         rows = self._decode(encoder_states, src_mask, tgt_inputs, tgt_mask, tgt_langs_t, batch_lang, proposals=proposals,
-                            pad_idx=self.text_processor.pad_token_id())
-        return self._loss_from_rows(rows, tgt_inputs, tgt_mask, batch_lang, epsilon)
+                            pad_idx=self.text_processor.pad_token_id(), sel_idx=sel_idx)
+        return self._loss_from_rows(rows, tgt_inputs, tgt_mask, batch_lang, epsilon, targets=targets)
 
-    def _loss_from_rows(self, rows, tgt_inputs, tgt_mask, batch_lang, epsilon):
-        targets = tgt_inputs[:, 1:][tgt_mask[:, 1:]].contiguous()
+    def _loss_from_rows(self, rows, tgt_inputs, tgt_mask, batch_lang, epsilon, targets=None):
+        if targets is None:
+            targets = tgt_inputs[:, 1:][tgt_mask[:, 1:]].contiguous()
         output_layer = self.output_layer if (not self.lang_dec) and self.tie_embed else self.output_layer[batch_lang]
         loss = _FusedXentFn.apply(rows, output_layer.layer.weight, output_layer.layer.bias, targets, float(epsilon),
                                   int(self.text_processor.pad_token_id()))
