@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
   const int64_t n4 = n & ~(int64_t)3;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += stride) {
     f32x4 pv = Vec4<float>::load(p + i), gv = Vec4<float>::load(g + i), mv = Vec4<float>::load(m + i), vv = Vec4<float>::load(v + i);
+    // untouched parameters (zero gradient and still-zero moments: the other language's output layer, vocabulary rows
+    // no batch has contained yet) get an exactly-zero update: nothing to write back (18 of 34 bytes per element saved)
+    bool idle = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) idle = idle && gv[e] == 0.f && mv[e] == 0.f && vv[e] == 0.f;
+    if (idle) continue;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float pe = pv[e], me = mv[e], ve = vv[e];
