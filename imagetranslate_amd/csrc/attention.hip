@@ -198,31 +198,6 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(A
   }
 }
 
-// =========================================================================================== delta = rowsum(dO * O)
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-  // one thread per (b, i, h, 4-element group); DH/4 consecutive lanes reduce one head
-  constexpr int LPH = DH / 4;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)p.B * p.Tq * p.H * LPH;
-  float v = 0.f;
-  int64_t bi = 0; int h = 0;
-  if (gid < total) {
-    const int c = (int)(gid % LPH);
-    h = (int)((gid / LPH) % p.H);
-    bi = gid / ((int64_t)LPH * p.H);
-    const f32x4 a = Vec4<T>::load(reinterpret_cast<const T*>(p.dO) + bi * p.lddo + h * DH + 4 * c);
-    const f32x4 o = Vec4<T>::load(reinterpret_cast<const T*>(p.O) + bi * p.ldo + h * DH + 4 * c);
-    v = a[0] * o[0] + a[1] * o[1] + a[2] * o[2] + a[3] * o[3];
-  }
-#pragma unroll
-  for (int off = LPH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  if (gid < total && (gid % LPH) == 0) {
-    const int64_t bb = bi / p.Tq, ii = bi % p.Tq;
-    p.delta[(bb * p.H + h) * p.Tq + ii] = v;
-  }
-}
-
 // =========================================================================================== backward: dQ
 template <typename T, int DH>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kernel(AttnP p) {

@@ -23,6 +23,22 @@ def main():
     mask = torch.ones(B, S, dtype=torch.bool)
     args = dict(src_inputs=src.cuda(), src_sizes=torch.full((B,), S), first_tokens=torch.full((B,), 5), src_mask=mask.cuda(),
                 src_langs=torch.zeros(B, dtype=torch.long).cuda(), tgt_langs=torch.ones(B, dtype=torch.long).cuda(), pad_idx=0)
+    from imagetranslate_amd import _lib as L
+    lib = L.load()
+    dec = BeamDecoder(model, beam_width=beam, kv_cache=True)
+    dec(max_len=8, **args)
+    torch.cuda.synchronize()
+    lib.imt_prof_enable(1)
+    out = dec(**args)
+    torch.cuda.synchronize()
+    rows = (L.ProfRow * 64)()
+    n = lib.imt_prof_report(rows, 64)
+    lib.imt_prof_enable(0)
+    steps = max(len(o) for o in out)
+    print("per-kernel device time of the cached search (%d steps):" % steps)
+    for r in sorted(rows[:n], key=lambda r: -r.total_ms):
+        print("  %-28s %6d launches %8.3f ms  (%.1f us each)" % (r.kind.decode(), r.launches, r.total_ms, 1e3 * r.total_ms / r.launches))
+    print("  total %.3f ms" % sum(r.total_ms for r in rows[:n]), flush=True)
     for kv, max_len in ((True, None), (False, None)):
         dec = BeamDecoder(model, beam_width=beam, kv_cache=kv)
         out = dec(max_len=8, **args)  # warm-up
