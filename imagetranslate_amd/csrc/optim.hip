@@ -7,7 +7,13 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// Deterministic: every workgroup writes ONE partial (fixed element->thread mapping, fixed in-block order) and a second
+// one-block kernel adds the partials in a fixed tree order.  (A float atomicAdd per workgroup made the global norm --
+// hence the clip coefficient, hence every parameter -- differ in the last bit between data-parallel ranks that hold
+// identical all-reduced gradients: replicas must stay bit-identical without ever re-synchronising parameters.)
+constexpr int SUMSQ_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
   __shared__ float red[4];
   float s = 0.f;
   const int64_t stride = (int64_t)gridDim.x * 1024;
@@ -21,7 +27,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 struct AdamP {
@@ -79,15 +95,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
 
 }  // namespace
 
-extern "C" int imt_sumsq(const float* g, int64_t n, float* out, void* stream) {
+extern "C" int imt_sumsq(const float* g, int64_t n, float* out, float* partial_ws, void* stream) {
   if (n <= 0) return IMT_OK;
-  IMT_CHECK_ARG(g && out, "sumsq: null pointer");
+  IMT_CHECK_ARG(g && out && partial_ws, "sumsq: null pointer");
   IMT_CHECK_ARG(((uintptr_t)g & 15) == 0, "sumsq: 16-B alignment");
   int blocks = imt_cdiv(n, 4096);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > SUMSQ_MAX_BLOCKS) blocks = SUMSQ_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   ImtProfScope prof("grad_sumsq", 0.0, 4.0 * n, (hipStream_t)stream);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, partial_ws);
+  IMT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial_ws, blocks, out);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }

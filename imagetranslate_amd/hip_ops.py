@@ -264,9 +264,11 @@ def xent_fused_fwd_bwd(logits, target, epsilon, ignore_index, grad_scale):
     return loss
 
 
-def sumsq(g, out):
-    _req_cuda(g, out)
-    L.check(L.load().imt_sumsq(_p(g), g.numel(), _p(out), _stream()), "imt_sumsq")
+def sumsq(g, out, ws=None):
+    _req_cuda(g, out, ws)
+    if ws is None:
+        ws = torch.empty(1024, device=g.device, dtype=torch.float32)  # IMT_SUMSQ_WS_FLOATS
+    L.check(L.load().imt_sumsq(_p(g), g.numel(), _p(out), _p(ws), _stream()), "imt_sumsq")
     return out
 
 

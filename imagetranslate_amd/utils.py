@@ -100,8 +100,9 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
             if max_grad_norm and max_grad_norm > 0:
                 if self._sumsq is None or self._sumsq.device != st.flat.device:
                     self._sumsq = torch.zeros(1, device=st.flat.device)
+                    self._sumsq_ws = torch.empty(1024, device=st.flat.device, dtype=torch.float32)
                 self._sumsq.zero_()
-                O.sumsq(st.grad, self._sumsq)
+                O.sumsq(st.grad, self._sumsq, self._sumsq_ws)
                 sumsq = self._sumsq
                 self.last_grad_norm_sq = sumsq
             O.clip_adam(st.flat, st.grad, m, v, st.shadow_buffer_for_optimizer(), sumsq, float(max_grad_norm or 0.0),

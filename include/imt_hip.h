@@ -200,13 +200,16 @@ int imt_xent_fused_fwd_bwd(int dtype, void* logits, int64_t ld, const int64_t* t
 
 /* ------------------------------------------------------------------ optimizer
  * (clip_grad_norm_ train_image_mt.py:291 ; AdamInverseSqrtWithWarmup src/utils.py:105-156)
- * imt_sumsq       : out[0] += sum(g^2) over n fp32 elements (out pre-zeroed by caller).
+ * imt_sumsq       : out[0] += sum(g^2) over n fp32 elements (out pre-zeroed by caller); DETERMINISTIC (fixed
+ *                   reduction order: data-parallel replicas holding identical gradients get identical norms);
+ *                   partial_ws = IMT_SUMSQ_WS_FLOATS floats of scratch.
  * imt_clip_adam   : clip_coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) ; g *= clip_coef ;
  *                   Adam(beta1, beta2, eps, no weight decay, bias-corrected) on fp32 master params ;
  *                   optionally writes the bf16 shadow copy ; optionally zeroes g.
  *                   lr and step are read from the host args (one launch per step).
  */
-int imt_sumsq(const float* g, int64_t n, float* out, void* stream);
+#define IMT_SUMSQ_WS_FLOATS 1024
+int imt_sumsq(const float* g, int64_t n, float* out, float* partial_ws, void* stream);
 int imt_clip_adam(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* sumsq,
                   float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, int64_t step,
                   int zero_grad, void* stream);
