@@ -143,11 +143,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     import torch.distributed as dist
+    # rehearsal knobs (NOT for measurements): IMT_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # IMT_BENCH_BACKEND=gloo carries the collectives, so the N > 1 control flow can be exercised on a one-GPU box
+    if os.environ.get("IMT_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("IMT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from imagetranslate_amd.parallel import GradSync, train_step
     from imagetranslate_amd.utils import AdamInverseSqrtWithWarmup
