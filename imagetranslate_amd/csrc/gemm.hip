@@ -180,7 +180,9 @@ template <typename T> struct ColSum {
 // (bias, residual, GELU aux, C) is a 16-B-per-lane (8 B for bf16 stores) access with 32 consecutive lanes per row.
 IMT_DEVICE int epi_off(int row, int c4) { return row * 512 + ((c4 ^ (row & 31)) << 4); }
 
-template <typename T>
+// NTHR threads share the group loop (256 = the MFMA waves alone; 512 = the persistent kernel's LAST tile, where its idle
+// producer waves help: HAS_ACC = false for them -- they hold no accumulators and only join from the first barrier on).
+template <typename T, int NTHR = NTHREADS, bool HAS_ACC = true>
 IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
                          float alpha, bool active = true) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
@@ -194,24 +196,25 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
   constexpr bool PREFETCH = (sizeof(T) == 2);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    raw_t zr[8], rr[8], br = raw_t{};
+    constexpr int GPT = 2048 / NTHR;  // 4-column groups per thread per 64-row pass
+    raw_t zr[GPT], rr[GPT], br = raw_t{};
     const bool pre = PREFETCH && active && !ep.atomic && (m0 + 64 * pass + 64 <= M) && (n0 + BN <= N);
     if (PREFETCH) {
 #pragma unroll
-      for (int gq = 0; gq < 8; ++gq) { zr[gq] = raw_t{}; rr[gq] = raw_t{}; }
+      for (int gq = 0; gq < GPT; ++gq) { zr[gq] = raw_t{}; rr[gq] = raw_t{}; }
       if (pre) {
         const int c4 = threadIdx.x & 31;
         if (bias) br = Vec4<T>::load_raw(bias + n0 + 4 * c4);
 #pragma unroll
-        for (int gq = 0; gq < 8; ++gq) {
-          const int64_t m = m0 + 64 * pass + ((gq * NTHREADS + (int)threadIdx.x) >> 5);
+        for (int gq = 0; gq < GPT; ++gq) {
+          const int64_t m = m0 + 64 * pass + ((gq * NTHR + (int)threadIdx.x) >> 5);
           if (ep.aux_mode == IMT_AUX_DGELU) zr[gq] = Vec4<T>::load_raw(aux + m * ep.ldaux + n0 + 4 * c4);
           if (resid) rr[gq] = Vec4<T>::load_raw(resid + m * ep.ldr + n0 + 4 * c4);
         }
       }
     }
     __syncthreads();  // previous users of smem (K loop / previous pass) are done
-    if (active && wm == 64 * pass) {
+    if (HAS_ACC && active && wm == 64 * pass) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -221,8 +224,8 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
     __syncthreads();
     if (!active) continue;
 #pragma unroll
-    for (int gq = 0; gq < 8; ++gq) {
-      const int idx = gq * NTHREADS + threadIdx.x;
+    for (int gq = 0; gq < GPT; ++gq) {
+      const int idx = gq * NTHR + threadIdx.x;
       const int row = idx >> 5, c4 = idx & 31;
       const int m = m0 + 64 * pass + row, n = n0 + 4 * c4;
       if (m >= M || n >= N) continue;
@@ -524,9 +527,18 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
       if (++t == nt) {
         t = 0;
-        // the consumers' epilogue: 2 passes x 2 barriers (+2 for the fused column sums)
-        asm volatile("s_barrier\n\ts_barrier\n\ts_barrier\n\ts_barrier" ::: "memory");
-        if (colsum_kernel) asm volatile("s_barrier\n\ts_barrier" ::: "memory");
+        if (q == total - 1) {
+          // last tile of this workgroup: nothing left to stream, so the producer waves take half of the epilogue's
+          // group loop (with one tile per CU -- every N = 512 GEMM of the step -- the epilogue is fully exposed)
+          const int lt = imt_xcd_block(blockIdx.x + (my_tiles - 1) * gridDim.x, tiles);
+          const f32x4 none[4][4] = {};
+          const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+          epilogue<T, 512, false>(none, epi, (lt / nbx) * BM, (lt % nbx) * BN, -1, 0, M, N, ep, alpha);
+        } else {
+          // the consumers' epilogue: 2 passes x 2 barriers
+          asm volatile("s_barrier\n\ts_barrier\n\ts_barrier\n\ts_barrier" ::: "memory");
+        }
+        if (colsum_kernel) asm volatile("s_barrier\n\ts_barrier" ::: "memory");  // + the fused column sums
       }
     }
   } else {
@@ -552,7 +564,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
         if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
         cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
       }
-      epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
+      if (i == my_tiles - 1) epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);  // producers join in
+      else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
       if (colsum_kernel) cs.flush(epi, ep.a_colsum, m0, M, alpha, do_colsum);
     }
   }
