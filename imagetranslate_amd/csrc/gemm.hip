@@ -199,6 +199,22 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
     constexpr int GPT = 2048 / NTHR;  // 4-column groups per thread per 64-row pass
     raw_t zr[GPT], rr[GPT], br = raw_t{};
     const bool pre = PREFETCH && active && !ep.atomic && (m0 + 64 * pass + 64 <= M) && (n0 + BN <= N);
+    // fp32 C += ... (weight gradients): the old C values are requested up front as well (8-wave epilogues only, where 4
+    // groups per thread keep it at 16 registers)
+    constexpr bool PREFETCH_C = (NTHR == 512);
+    f32x4 cr[PREFETCH_C ? GPT : 1];
+    const bool pre_c = PREFETCH_C && active && !ep.atomic && ep.accumulate && ep.c_f32 && (m0 + 64 * pass + 64 <= M) && (n0 + BN <= N);
+    if (PREFETCH_C) {
+#pragma unroll
+      for (int gq = 0; gq < GPT; ++gq) cr[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pre_c) {
+#pragma unroll
+        for (int gq = 0; gq < GPT; ++gq) {
+          const int64_t m = m0 + 64 * pass + ((gq * NTHR + (int)threadIdx.x) >> 5);
+          cr[gq] = Vec4<float>::load(reinterpret_cast<const float*>(ep.C) + m * ep.ldc + n0 + 4 * (threadIdx.x & 31));
+        }
+      }
+    }
     if (PREFETCH) {
 #pragma unroll
       for (int gq = 0; gq < GPT; ++gq) { zr[gq] = raw_t{}; rr[gq] = raw_t{}; }
@@ -256,7 +272,7 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
         if (resid) v += pre ? Vec4<T>::cvt(rr[gq]) : Vec4<T>::load(resid + (int64_t)m * ep.ldr + n);
         if (ep.c_f32) {
           float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
-          if (ep.accumulate) v += Vec4<float>::load(c);
+          if (ep.accumulate) v += pre_c ? cr[PREFETCH_C ? gq : 0] : Vec4<float>::load(c);
           Vec4<float>::store(c, v);
         } else {
           T* c = reinterpret_cast<T*>(ep.C) + (int64_t)m * ep.ldc + n;
@@ -657,7 +673,9 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
   ep.bias = nullptr; ep.resid = nullptr; ep.ldr = 0; ep.aux = nullptr; ep.ldaux = 0; ep.aux_mode = IMT_AUX_NONE;
   ep.atomic = 0; ep.alpha = g.alpha; ep.alpha_dev = nullptr; ep.inv_keep = 1.f; ep.drop_thresh = 0; ep.seed = 0;
   ep.a_colsum = P.a_colsum; ep.dbg = 0;
-  epilogue<T>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha, consumer);
+  // one tile per workgroup: the epilogue is fully exposed, so all 8 waves share it (the producers have nothing left to do)
+  if (consumer) epilogue<T, 512, true>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
+  else epilogue<T, 512, false>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
   if (do_colsum) cs.flush(smem, P.a_colsum, m0, M, g.alpha, consumer);
 }
 
