@@ -8,13 +8,19 @@
 // (mfma(Bfrag, Afrag)) so each lane owns 4 consecutive n of one m: bias / residual / aux accesses and the C
 // store are 8- or 16-byte vectors.
 //
-// Two main loops share the tile compute and the epilogue:
-//   gemm_pipe_kernel : LDS-DMA (buffer_load ... lds, 16 B/lane) into a 3-stage ring; tile t+2 is in flight while
-//                      tile t is multiplied; ONE raw s_barrier per K tile and a COUNTED s_waitcnt vmcnt(8) so the
-//                      prefetch survives the barrier (cdna guide: "Pipelining across barriers").  The swizzle is
-//                      applied to the per-lane SOURCE address (the DMA destination is lane-linear).  Used whenever
-//                      the K extent of a block is a whole number of tiles.
-//   gemm_kernel      : register-staged double buffer with predicated (zero-filling) loads: ragged K / tiny K.
+// Five main loops share the tile product (compute_tile) and the LDS-restaged epilogue; imt_gemm picks one per shape
+// from measurements (profiles/r01_v5_gemm_shapes.txt, profiles/r01_gemm_epilogue_study.txt):
+//   gemm_ws_kernel         : persistent, wave-specialised -- 4 MFMA waves + 4 LDS-DMA producer waves (buffer_load ... lds,
+//                            16 B/lane, swizzle on the SOURCE address, 4-stage ring, one raw s_barrier per K tile, counted
+//                            vmcnt on the producers); on a workgroup's last tile the idle producers share the epilogue.
+//                            K a whole number of tiles and (<= one tile per CU or K >= 1024).
+//   gemm_grouped_tn_kernel : the same split for ALL weight-gradient products of a layer in one launch (full K per tile,
+//                            fp32 accumulate, fused bias gradients).
+//   gemm_sb_kernel         : one 32-KiB LDS buffer + register prefetch, three workgroups per CU overlap each other's
+//                            barriers and epilogues: many short-K tiles.
+//   gemm_kernel            : register-staged double buffer with predicated (zero-filling) loads: ragged / tiny K, split-K.
+//   gemm_pipe_kernel       : LDS-DMA ring issued by the MFMA waves themselves (superseded by gemm_ws_kernel; kept as a
+//                            cross-check variant for the tests).
 #include <stdlib.h>
 #include "mma.hpp"
 

@@ -122,12 +122,12 @@ def layernorm_fwd(x, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, y_dropout_p=0.0, y_dropout_seed=0, want_dx_drop=False,
-                  dx_dropout_p=0.0, dx_dropout_seed=0, two_stage=False):
+                  dx_dropout_p=0.0, dx_dropout_seed=0):
     _req_cuda(dy, x, gamma, dgamma, dbeta)
     rows, d = x.shape
     dx = torch.empty_like(x)
     dx_drop = torch.empty_like(x) if want_dx_drop else None
-    ws = torch.empty(1024 * 2 * d, device=x.device, dtype=torch.float32) if two_stage else None
+    ws = None  # partial_ws is reserved (include/imt_hip.h)
     L.check(L.load().imt_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                        _p(dbeta), rows, d, y_dropout_p, y_dropout_seed, _p(dx_drop), dx_dropout_p,
                                        dx_dropout_seed, _p(ws), _stream()), "imt_layernorm_bwd")

@@ -309,8 +309,8 @@ def test_layernorm(cuda, dtype, d):
     assert_close(dx, xr.grad, tol * 2, "ln dx")
     assert_close(dgamma, gr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dgamma")
     assert_close(dbeta, br.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dbeta")
-    # accumulation semantics: second call (two-stage reduction path) doubles the parameter grads
-    O.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, two_stage=True)
+    # accumulation semantics: a second call doubles the parameter grads
+    O.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta)
     assert_close(dgamma, 2 * gr.grad, 1e-4 if dtype == torch.float32 else 1e-2, "ln dgamma accum")
 
 

@@ -28,7 +28,6 @@ for dt in ((torch.bfloat16,) if __name__ == "__main__" else ()):
     es = 2
     t = timeit(lambda: O.layernorm_fwd(x, g, b)); print("ln_fwd            %7.1f us  %6.0f GB/s" % (t, 2 * rows * d * es / t / 1e3))
     t = timeit(lambda: O.layernorm_bwd(dy, x, g, mean, rstd, dg, db)); print("ln_bwd atomics    %7.1f us  %6.0f GB/s" % (t, 3 * rows * d * es / t / 1e3))
-    t = timeit(lambda: O.layernorm_bwd(dy, x, g, mean, rstd, dg, db, two_stage=True)); print("ln_bwd two-stage  %7.1f us  %6.0f GB/s" % (t, 3 * rows * d * es / t / 1e3))
     t = timeit(lambda: O.layernorm_bwd(dy, x, g, mean, rstd, dg, db, want_dx_drop=True, dx_dropout_p=0.1, dx_dropout_seed=5)); print("ln_bwd +dropout   %7.1f us  %6.0f GB/s" % (t, 4 * rows * d * es / t / 1e3))
     out = torch.zeros(d, device="cuda")
     t = timeit(lambda: O.colsum(dy, out)); print("colsum            %7.1f us  %6.0f GB/s" % (t, rows * d * es / t / 1e3))
