@@ -203,6 +203,50 @@ def test_vocabulary_size_not_a_multiple_of_eight(cuda, V):
     assert [g.tolist() for g in got] == [e.tolist() for e in exp]
 
 
+@pytest.mark.parametrize("variant", [dict(lang_dec=True), dict(lang_dec=True, tie_embed=True), dict(lang_dec=False, tie_embed=True)])
+def test_topology_variants_forward_backward_and_beam(cuda, variant):
+    """Per-language decoders (deep copies, src/seq2seq.py:67-77) and the --tie quirk (:55-59): log-probs, loss and
+    gradients against the oracle (fp32), training through the fused path, and beam search on the chosen decoder."""
+    import imagetranslate_amd.seq2seq as S
+    from imagetranslate_amd.seq_gen import BeamDecoder
+    from oracle.seq_gen import BeamDecoder as OracleBeam
+    torch.manual_seed(3)
+    tp = R.SyntheticTextProcessor(1000)
+    kw = dict(enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512, num_attention_heads=4, **variant)
+    ref = R.Seq2Seq(tp, **kw).eval()
+    ours = S.Seq2Seq(tp, **kw)
+    missing = ours.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    ours = ours.cuda().eval()
+    b = _toy_batch()
+    args = (b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
+    lp_ref, lp = ref(*args, log_softmax=True), ours(*args, log_softmax=True)
+    assert_close(lp, lp_ref, 1e-4, "log-probs")
+    assert torch.equal(lp.argmax(-1).cpu(), lp_ref.argmax(-1))
+    targets = b["dst_texts"][:, 1:].contiguous().view(-1)[b["dst_pad_mask"][:, 1:].contiguous().view(-1)]
+    loss_ref = R.SmoothedNLLLoss(ignore_index=0)(lp_ref, targets).mean()
+    loss_ref.backward()
+    loss, ntok = ours.loss_fused(*args)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(loss_ref.detach()), rel=1e-5) and ntok == lp.shape[0]
+    checked = 0
+    ref_named = dict(ref.named_parameters())
+    for k, p in ours.named_parameters():
+        g_ref = ref_named[k].grad
+        if g_ref is None or float(g_ref.abs().max()) < 1e-9:  # the other language's copies; key biases (softmax shift invariance)
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, "unexpected gradient on " + k
+            continue
+        assert_close(p.grad, g_ref, 3e-4, "grad " + k)
+        checked += 1
+    assert checked > 40
+    n = 4
+    bk = dict(src_inputs=b["src_texts"][:n], src_sizes=b["src_pad_mask"][:n].sum(1), first_tokens=torch.full((n,), 6),
+              src_mask=b["src_pad_mask"][:n], src_langs=b["src_langs"][:n], tgt_langs=b["dst_langs"][:n], pad_idx=0, max_len=8)
+    exp = OracleBeam(ref, beam_width=3)(**bk)
+    got = BeamDecoder(ours, beam_width=3)(**bk)
+    assert [g.tolist() for g in got] == [e.tolist() for e in exp]
+
+
 def test_bf16_mode_tracks_fp32(cuda):
     ref, ours = _pair()
     ours.set_compute_dtype(torch.bfloat16)
