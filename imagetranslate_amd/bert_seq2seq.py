@@ -268,7 +268,13 @@ class _StackFn(torch.autograd.Function):
             io.enc_mask = enc_mask.data_ptr() if enc_mask is not None else None
         io.Tk = Tk
         io.dropout_seed = seed
-        params = store.params_for(dtype)
+        # lowest flat offset this stack reads (its own parameters come first, the shared encoder blocks / embeddings
+        # later): lets an optimizer step that is still running on its side stream finish the other segments meanwhile
+        lo_key = ("_imt_params_lo", store.layout_version)
+        if mod.__dict__.get("_imt_params_lo_key") != lo_key:
+            mod.__dict__["_imt_params_lo"] = min(store.offset(p) for p in mod.parameters())
+            mod.__dict__["_imt_params_lo_key"] = lo_key
+        params = store.params_for(dtype, lo=mod.__dict__["_imt_params_lo"])
         desc.params = params.data_ptr()
         desc.grads = store.grad.data_ptr()
         lib = L.load()

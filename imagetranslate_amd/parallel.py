@@ -11,6 +11,7 @@ backward is issued layer by layer; after each layer a hook hands the newly final
 all-reduce (RCCL runs it on its own stream, overlapped with the remaining backward kernels).  The 1/world_size is
 folded into the fused clip+Adam kernel (``grad_scale``), so there is no separate scaling pass.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -123,5 +124,6 @@ def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: f
     scale = 1.0
     if sync is not None:
         scale = sync.finish()
-    optimizer.step(max_grad_norm=clip, grad_scale=scale, zero_grad=True)
+    optimizer.step(max_grad_norm=clip, grad_scale=scale, zero_grad=True,
+                   overlap_next_forward=os.environ.get("IMT_ADAM_OVERLAP", "1") != "0")
     return loss, ntokens

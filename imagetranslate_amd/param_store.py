@@ -35,6 +35,7 @@ class FlatParams:
         self.index = {}        # id(param) -> offset
         self.total = 0
         self.layout_version = 0
+        self._update_events = []  # (lo, hi, event) of an optimizer step still running on its side stream
 
     # ------------------------------------------------------------------ layout
     def _ordered_params(self) -> List[nn.Parameter]:
@@ -115,15 +116,30 @@ class FlatParams:
                 p.grad = self.grad[off:off + n].view(p.shape)
 
     def zero_grad(self):
+        self.wait_updates(0)
         if self.grad is not None:
             self.grad.zero_()
 
     def mark_master_changed(self):
         self._shadow_stale = True
 
-    def params_for(self, dtype: torch.dtype) -> torch.Tensor:
+    def wait_updates(self, lo: int = 0):
+        """Make the current stream wait for the part of an overlapped optimizer step (AdamInverseSqrtWithWarmup.step(
+        overlap_next_forward=True)) that writes parameters at offsets >= lo.  Events complete in the order the segments
+        were issued (highest offsets first), so a consumer of [lo, total) waits for every segment reaching above lo."""
+        if self._update_events:
+            cur = torch.cuda.current_stream()
+            for seg_lo, seg_hi, ev in self._update_events:
+                if seg_hi > lo:
+                    cur.wait_event(ev)
+            if lo == 0:
+                self._update_events = []
+
+    def params_for(self, dtype: torch.dtype, lo: int = 0) -> torch.Tensor:
         """Flat parameter buffer in the compute dtype (fp32 master itself, or the bf16 shadow, refreshed when the
-        master changed through torch in-place ops or a fused optimizer step without shadow write)."""
+        master changed through torch in-place ops or a fused optimizer step without shadow write).  ``lo``: the caller
+        only reads parameters at offsets >= lo (see wait_updates)."""
+        self.wait_updates(lo)
         if dtype == torch.float32:
             return self.flat
         assert dtype == torch.bfloat16

@@ -357,6 +357,12 @@ class Seq2Seq(nn.Module):
                                   int(self.text_processor.pad_token_id()))
         return loss, int(targets.numel())
 
+    def state_dict(self, *args, **kwargs):
+        st = self.__dict__.get("_imt_flat_store")
+        if st is not None:
+            st.wait_updates(0)  # an overlapped optimizer step (side stream) must have landed before parameters are read
+        return super().state_dict(*args, **kwargs)
+
     def save(self, out_dir: str):
         if not os.path.exists(out_dir):
             os.makedirs(out_dir)

@@ -84,7 +84,12 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
             super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
-    def step(self, closure=None, max_grad_norm: float = 0.0, grad_scale: float = 1.0, zero_grad: bool = False):
+    def step(self, closure=None, max_grad_norm: float = 0.0, grad_scale: float = 1.0, zero_grad: bool = False,
+             overlap_next_forward: bool = False):
+        """``overlap_next_forward`` (fused path only): the update runs on a side stream in three segments -- encoder +
+        embeddings, decoder, output layers -- and each stack of the NEXT forward waits only for the segments it reads
+        (FlatParams.wait_updates), so the HBM-bound update of the decoder / output layers runs under the encoder's
+        latency-bound kernels.  Same arithmetic, same order of operations per parameter."""
         if closure is not None:
             raise ValueError("closures are not supported")
         st = self._store()
@@ -105,9 +110,30 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
                 O.sumsq(st.grad, self._sumsq, self._sumsq_ws)
                 sumsq = self._sumsq
                 self.last_grad_norm_sq = sumsq
-            O.clip_adam(st.flat, st.grad, m, v, st.shadow_buffer_for_optimizer(), sumsq, float(max_grad_norm or 0.0),
-                        float(grad_scale), float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], step,
-                        zero_grad=zero_grad)
+            segs = self._segments(st) if overlap_next_forward else None
+            if segs is None:
+                O.clip_adam(st.flat, st.grad, m, v, st.shadow_buffer_for_optimizer(), sumsq, float(max_grad_norm or 0.0),
+                            float(grad_scale), float(g['lr']), g['betas'][0], g['betas'][1], g['eps'], step,
+                            zero_grad=zero_grad)
+            else:
+                main = torch.cuda.current_stream()
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream()
+                st.wait_updates(0)
+                done = torch.cuda.Event()
+                done.record(main)           # backward, all-reduce and the grad norm are enqueued before this point
+                self._side.wait_event(done)
+                sh = st.shadow_buffer_for_optimizer()
+                events = []
+                with torch.cuda.stream(self._side):
+                    for lo, hi in segs:     # highest offsets first: what the next forward needs first
+                        O.clip_adam(st.flat[lo:hi], st.grad[lo:hi], m[lo:hi], v[lo:hi], None if sh is None else sh[lo:hi], sumsq,
+                                    float(max_grad_norm or 0.0), float(grad_scale), float(g['lr']), g['betas'][0], g['betas'][1],
+                                    g['eps'], step, zero_grad=zero_grad)
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                        events.append((lo, hi, ev))
+                st._update_events = events
             if st.shadow_buffer_for_optimizer() is not None:
                 st.note_shadow_written_by_optimizer()
             else:
@@ -115,6 +141,22 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
         for param_group in self.param_groups:
             param_group['num_updates'] += 1
             param_group['lr'] = self.get_lr_for_step(param_group['num_updates'])
+
+    @staticmethod
+    def _segments(st):
+        """[(lo, hi)] of the flat buffer in the order the next forward needs them: encoder + embeddings (and whatever
+        follows), decoder(s), output layers -- None when the model does not expose that structure."""
+        root = st._root()
+        try:
+            enc_first = list(root.encoder.encoder.layer)[-1].ordered_params()[0]
+            decs = list(root.decoder) if isinstance(root.decoder, torch.nn.ModuleList) else [root.decoder]
+            dec_lo = min(st.offset(p) for d in decs for p in d.parameters())
+            enc_lo = st.offset(enc_first)
+        except Exception:
+            return None
+        if not (0 < dec_lo < enc_lo < st.total):
+            return None
+        return [(enc_lo, st.total), (dec_lo, enc_lo), (0, dec_lo)]
 
     def _generic_step(self, max_grad_norm, grad_scale):
         params = [p for g in self.param_groups for p in g['params'] if p.grad is not None]

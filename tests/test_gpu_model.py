@@ -247,6 +247,35 @@ def test_topology_variants_forward_backward_and_beam(cuda, variant):
     assert [g.tolist() for g in got] == [e.tolist() for e in exp]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_overlapped_optimizer_step_matches_in_order_step(cuda, dtype):
+    """optimizer.step(overlap_next_forward=True) -- segments on a side stream, each stack of the next forward waiting
+    only for what it reads -- must leave the parameters of the in-order step, step after step.  (Not bit-for-bit: the
+    embedding / LayerNorm gradients are atomic sums whose order varies run to run; a stale-parameter race would show
+    at the scale of the updates, 1e-3, not 1e-7.)"""
+    from imagetranslate_amd.utils import AdamInverseSqrtWithWarmup
+    results = []
+    for overlap in (False, True):
+        _, ours = _pair()
+        ours.set_compute_dtype(dtype)
+        ours.train()
+        for mod in (ours.encoder, ours.decoder):
+            mod._imt_dropout_seed = 123  # same dropout masks in both runs
+        opt = AdamInverseSqrtWithWarmup(ours.parameters(), lr=1e-3, betas=(0.9, 0.98), warmup_updates=2)
+        losses = []
+        for step in range(4):
+            b = _toy_batch(seed=50 + step)
+            loss, _ = ours.loss_fused(b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
+            loss.backward()
+            opt.step(max_grad_norm=1.0, zero_grad=True, overlap_next_forward=overlap)
+            losses.append(float(loss.detach()))
+        results.append((losses, {k: v.detach().clone() for k, v in ours.state_dict().items()}))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-5), "losses differ: %s vs %s" % (results[0][0], results[1][0])
+    for k, v in results[0][1].items():
+        diff = float((v.float() - results[1][1][k].float()).abs().max())
+        assert diff <= 2e-6 * max(1.0, float(v.float().abs().max())) + (1e-5 if dtype == torch.bfloat16 else 0.0), (k, diff)
+
+
 def test_bf16_mode_tracks_fp32(cuda):
     ref, ours = _pair()
     ours.set_compute_dtype(torch.bfloat16)
