@@ -276,6 +276,38 @@ def test_overlapped_optimizer_step_matches_in_order_step(cuda, dtype):
         assert diff <= 2e-6 * max(1.0, float(v.float().abs().max())) + (1e-5 if dtype == torch.bfloat16 else 0.0), (k, diff)
 
 
+@pytest.mark.parametrize("B,S,T", [(2, 512, 512), (1, 1, 2), (3, 7, 2), (2, 130, 129)])
+def test_extreme_lengths_fp32_parity(cuda, B, S, T):
+    """Maximum length (max_position_embeddings = 512: multi-tile attention, two-kernel backward), the shortest legal
+    batch (one source token, one target transition), and lengths just past a tile boundary; ragged padding throughout."""
+    ref, ours = _pair()
+    g = torch.Generator().manual_seed(S * 1000 + T)
+    src = torch.randint(6, 1000, (B, S), generator=g)
+    tgt = torch.randint(6, 1000, (B, T), generator=g)
+    if S > 4:
+        src[0, S - S // 3:] = 0
+    if T > 4:
+        tgt[-1, T - T // 4:] = 0
+    args = (src, tgt, src != 0, tgt != 0, torch.zeros(B, dtype=torch.long), torch.ones(B, dtype=torch.long))
+    lp_ref, lp = ref(*args, log_softmax=True), ours(*args, log_softmax=True)
+    assert lp.shape == lp_ref.shape
+    assert_close(lp, lp_ref, 1e-4, "log-probs")
+    assert torch.equal(lp.argmax(-1).cpu(), lp_ref.argmax(-1))
+    targets = tgt[:, 1:][(tgt != 0)[:, 1:]]
+    loss_ref = R.SmoothedNLLLoss(ignore_index=0)(lp_ref, targets).mean()
+    loss_ref.backward()
+    loss, ntok = ours.loss_fused(*args)
+    loss.backward()
+    assert ntok == targets.numel() and float(loss.detach()) == pytest.approx(float(loss_ref.detach()), rel=2e-5)
+    for k in ["encoder.embeddings.position_embeddings.weight", "encoder.encoder.layer.1.attention.self.value.weight",
+              "decoder.decoder.layer.0.crossattention.self.query.weight", "output_layer.1.layer.bias"]:
+        g_ref = _grad_of(ref, k)
+        if float(g_ref.abs().max()) < 1e-9:  # exactly zero in theory (softmax over a single key has no query gradient)
+            assert float(_grad_of(ours, k).abs().max()) < 1e-6, k
+        else:
+            assert_close(_grad_of(ours, k), g_ref, 3e-4, "grad " + k)
+
+
 def test_bf16_mode_tracks_fp32(cuda):
     ref, ours = _pair()
     ours.set_compute_dtype(torch.bfloat16)
