@@ -6,33 +6,20 @@ BASELINE's d=512/h=8 and d=128/h=4 configurations unconstructible); the default 
 from typing import Dict
 
 
-def _bert_config(vocab_size: int, pad_token_id: int, bos_token_id: int, eos_token_id: int) -> Dict:
-    return {
-        "attention_probs_dropout_prob": 0.1,
-        "hidden_act": "gelu",
-        "hidden_dropout_prob": 0.1,
-        "hidden_size": 768,
-        "initializer_range": 0.02,
-        "intermediate_size": 3072,
-        "max_position_embeddings": 512,
-        "num_attention_heads": 12,
-        "num_hidden_layers": 6,
-        "vocab_size": vocab_size,
-        "pad_token_id": pad_token_id,
-        "bos_token_id": bos_token_id,
-        "eos_token_id": eos_token_id,
-    }
+# (field, value) pairs the reference fixes for every model (src/lm_config.py:4-21); the four model-size fields are
+# filled in by get_config from the constructor arguments of Seq2Seq.
+_FIXED = (("hidden_act", "gelu"), ("initializer_range", 0.02), ("max_position_embeddings", 512),
+          ("hidden_dropout_prob", 0.1), ("attention_probs_dropout_prob", 0.1))
 
 
 def get_config(vocab_size: int, pad_token_id: int, bos_token_id: int, eos_token_id: int, enc_layer: int = 6,
                embed_dim: int = 768, intermediate_dim: int = 3072, num_attention_heads: int = 12) -> Dict:
-    config = _bert_config(vocab_size=vocab_size, pad_token_id=pad_token_id, bos_token_id=bos_token_id,
-                          eos_token_id=eos_token_id)
-    config["num_hidden_layers"] = enc_layer
-    config["intermediate_size"] = intermediate_dim
-    config["hidden_size"] = embed_dim
-    config["num_attention_heads"] = num_attention_heads
-    return config
+    """Plain dict in the shape transformers.BertConfig(**d) takes (what src/seq2seq.py:37 does with it)."""
+    cfg = dict(_FIXED)
+    cfg.update(hidden_size=embed_dim, intermediate_size=intermediate_dim, num_hidden_layers=enc_layer,
+               num_attention_heads=num_attention_heads)
+    cfg.update(vocab_size=vocab_size, pad_token_id=pad_token_id, bos_token_id=bos_token_id, eos_token_id=eos_token_id)
+    return cfg
 
 
 class BertConfig:
