@@ -198,6 +198,101 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(A
   }
 }
 
+// =========================================================================================== forward, short sequences
+// Tq, Tk <= 128, bf16: one workgroup (8 waves, 16 queries each) per (batch, head).  K and V are staged ONCE for all
+// 128 queries (the 64-query kernel above stages them once per query tile), and with every key resident the softmax is
+// a single pass: all S^T tiles, one max, one exp/sum, then O^T = V^T P^T -- no running rescale.
+template <int DH>
+__global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
+  typedef bf16_t T;
+  constexpr int RB = DH * 2, NS = RB / 64, NDT = DH / 16;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char Ks[128 * RB];
+  __shared__ __attribute__((aligned(16))) char Vs[128 * RB];
+  __shared__ uint8_t kmask_s[128];
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);
+  const int b = lid / p.H, h = lid % p.H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int q0 = wave * 16, i = q0 + r;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
+  {
+    constexpr int CPR = RB / 16;
+    for (int q = threadIdx.x; q < 128 * CPR; q += 512) {
+      const int tr = q / CPR, c = q % CPR;
+      u32x4 vk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+      if (tr < p.Tk) {
+        vk = *reinterpret_cast<const u32x4*>(Kb + (int64_t)tr * p.ldk + c * 8);
+        vv = *reinterpret_cast<const u32x4*>(Vb + (int64_t)tr * p.ldv + c * 8);
+      }
+      *reinterpret_cast<u32x4*>(Ks + tile_off<RB>(tr, c)) = vk;
+      *reinterpret_cast<u32x4*>(Vs + tile_off<RB>(tr, c)) = vv;
+    }
+    if (threadIdx.x < 128) {
+      const int j = threadIdx.x;
+      kmask_s[j] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
+    }
+  }
+  frag_t qf[NS];
+  load_row_frags<T, DH>(qf, Qb, p.ldq, q0, p.Tq);
+  const bool query_ok = (p.query_mask && i < p.Tq) ? (p.query_mask[(int64_t)b * p.Tq + i] != 0) : true;
+  __syncthreads();
+  if (q0 >= p.Tq) return;  // whole wave past the last query (no barrier follows)
+
+  // S^T: 8 tiles of 16 keys x this wave's 16 queries
+  f32x4 s[8];
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) mma16(s[nt], lds_frag_kcontig<T, RB>(Ks, 16 * nt, 4 * ks), qf[ks]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 16 * nt + 4 * g + e;
+      float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_s[j] != 0, query_ok) ? 0.f : -10000.0f);
+      if (j >= p.Tk) v = -INFINITY;
+      s[nt][e] = v;
+      tmax = fmaxf(tmax, v);
+    }
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+  float psum = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pv = __expf(s[nt][e] - tmax);
+      psum += pv;
+      if (p.drop_thresh) {
+        const int j = 16 * nt + 4 * g + e;
+        const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
+        pv = dropout_keep(p.seed, idx, p.drop_thresh) ? pv * p.inv_keep : 0.f;
+      }
+      s[nt][e] = pv;
+    }
+  psum += __shfl_xor(psum, 16, 64);
+  psum += __shfl_xor(psum, 32, 64);
+  f32x4 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // 32 keys per MFMA k-step
+    const frag_t pf = acc_pair_to_frag(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) mma16(o[dt], lds_frag_kperm_bf16<RB>(Vs, 32 * u, 16 * dt), pf);
+  }
+  const float inv_l = 1.0f / psum;
+  if (i < p.Tq) {
+    T* Ob = reinterpret_cast<T*>(p.O) + ((int64_t)b * p.Tq + i) * p.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(Ob + 16 * dt + 4 * g, o[dt] * inv_l);
+    if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Tq + i] = tmax + __logf(psum);
+  }
+}
+
 // =========================================================================================== backward: dQ
 template <typename T, int DH>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kernel(AttnP p) {
@@ -660,6 +755,14 @@ extern "C" int imt_attention_fwd(const imt_attn_args* a, void* stream) {
   const AttnP p = make_params(a);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == IMT_F32) return a->head_dim == 32 ? fwd_launch<float, 32>(p, st) : fwd_launch<float, 64>(p, st);
+  if (a->Tq <= 128 && a->Tk <= 128 && a->Tq > 64 && !getenv("IMT_ATTN_NO_SHORT_FWD")) {  // one workgroup per (batch, head)
+    const double work = (double)p.B * p.H * p.Tq * p.Tk * a->head_dim;
+    ImtProfScope prof("attn_fwd_bf16", 4.0 * work, ((double)p.B * p.H * a->head_dim * 2.0) * (2.0 * p.Tq + 2.0 * p.Tk), st);
+    if (a->head_dim == 32) hipLaunchKernelGGL(attn_fwd_short_kernel<32>, dim3(p.B * p.H), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_short_kernel<64>, dim3(p.B * p.H), dim3(512), 0, st, p);
+    IMT_CHECK_LAUNCH();
+    return IMT_OK;
+  }
   return a->head_dim == 32 ? fwd_launch<bf16_t, 32>(p, st) : fwd_launch<bf16_t, 64>(p, st);
 }
 
