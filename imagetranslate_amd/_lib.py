@@ -69,7 +69,7 @@ class AttnBlock(Structure):
 class LayerDesc(Structure):
     _fields_ = [("self_attn", AttnBlock), ("cross_attn", AttnBlock),
                 ("ff1_w", c_int64), ("ff1_b", c_int64), ("ff2_w", c_int64), ("ff2_b", c_int64),
-                ("ln2_g", c_int64), ("ln2_b", c_int64)]
+                ("ln2_g", c_int64), ("ln2_b", c_int64), ("cross_kv_w", c_int64), ("cross_kv_b", c_int64)]
 
 
 class StackDesc(Structure):

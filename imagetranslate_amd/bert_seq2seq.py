@@ -58,8 +58,10 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(config)
         self.output = BertSelfOutput(config)
 
-    def ordered_params(self):
+    def ordered_params(self, with_key_value=True):
         s, o = self.self, self.output
+        if not with_key_value:  # cross-attention whose key|value projections are grouped across layers (see Seq2Seq)
+            return [s.query.weight, s.query.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias]
         return [s.query.weight, s.key.weight, s.value.weight, s.query.bias, s.key.bias, s.value.bias,
                 o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias]
 
@@ -88,10 +90,10 @@ class BertLayer(nn.Module):
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
 
-    def ordered_params(self, with_self_attention=True):
+    def ordered_params(self, with_self_attention=True, with_cross_key_value=True):
         ps = []
         if self.is_decoder:
-            ps += self.crossattention.ordered_params()
+            ps += self.crossattention.ordered_params(with_key_value=with_cross_key_value)
         ps += [self.intermediate.dense.weight, self.intermediate.dense.bias, self.output.dense.weight,
                self.output.dense.bias, self.output.LayerNorm.weight, self.output.LayerNorm.bias]
         if with_self_attention:
@@ -142,14 +144,24 @@ def _contig_after(store, first, rest):
     return off
 
 
-def _attn_block(store, att: BertAttention) -> L.AttnBlock:
+def _attn_block(store, att: BertAttention, split_kv: bool = False):
+    """Offsets of one attention block.  split_kv (cross-attention only): key|value need not follow the query projection;
+    returns (block, kv_w, kv_b) with kv_* = -1 when they do follow it."""
     s, o = att.self, att.output
     b = L.AttnBlock()
-    b.qkv_w = _contig_after(store, s.query.weight, [s.key.weight, s.value.weight])
-    b.qkv_b = _contig_after(store, s.query.bias, [s.key.bias, s.value.bias])
+    kv_w = kv_b = -1
+    follows = (store.offset(s.key.weight) == store.offset(s.query.weight) + s.query.weight.numel()
+               and store.offset(s.key.bias) == store.offset(s.query.bias) + s.query.bias.numel())
+    if split_kv and not follows:
+        b.qkv_w, b.qkv_b = store.offset(s.query.weight), store.offset(s.query.bias)
+        kv_w = _contig_after(store, s.key.weight, [s.value.weight])
+        kv_b = _contig_after(store, s.key.bias, [s.value.bias])
+    else:
+        b.qkv_w = _contig_after(store, s.query.weight, [s.key.weight, s.value.weight])
+        b.qkv_b = _contig_after(store, s.query.bias, [s.key.bias, s.value.bias])
     b.o_w, b.o_b = store.offset(o.dense.weight), store.offset(o.dense.bias)
     b.ln_g, b.ln_b = store.offset(o.LayerNorm.weight), store.offset(o.LayerNorm.bias)
-    return b
+    return (b, kv_w, kv_b) if split_kv else b
 
 
 class _Pretrained(nn.Module):
@@ -195,8 +207,9 @@ class _Pretrained(nn.Module):
         for i, lyr in enumerate(layers):
             ld = arr[i]
             ld.self_attn = _attn_block(store, lyr.attention)
+            ld.cross_kv_w = ld.cross_kv_b = -1
             if getattr(lyr, "is_decoder", False):
-                ld.cross_attn = _attn_block(store, lyr.crossattention)
+                ld.cross_attn, ld.cross_kv_w, ld.cross_kv_b = _attn_block(store, lyr.crossattention, split_kv=True)
             else:
                 ld.cross_attn.qkv_w = -1
             ld.ff1_w, ld.ff1_b = store.offset(lyr.intermediate.dense.weight), store.offset(lyr.intermediate.dense.bias)

@@ -21,6 +21,7 @@ struct Carver {
 struct AttnWs {  // one attention block (self or cross)
   void* qkv;     // self: [N,3d] ; cross: q [N,d] then kv [Nk,2d]
   void* kv;      // cross only
+  int64_t kv_ld; // leading dimension of kv (2d, or L*2d when the projections of all layers are one buffer)
   void* ctx;     // [N,d]
   float* lse;    // [B,H,T]
   void* pre_ln;  // [N,d]  dense + residual (LN input)
@@ -45,6 +46,7 @@ struct StackWs {
   void* d_qkv;                       // [N,3d]
   void* d_q;                         // [N,d]   cross-attention query gradient
   void* d_kv;                        // [Nk,2d]
+  void* kv_all; void* d_kv_all;      // [Nk, L*2d] when the cross-attention key|value projections are batched
   float* delta;                      // [B,H,T]
   float* ln_partial;                 // IMT_LN_BWD_WS_FLOATS(d)
   int64_t bytes;
@@ -54,12 +56,33 @@ constexpr int MAX_LAYERS = 64;
 
 int64_t esize(int dtype) { return dtype == IMT_BF16 ? 2 : 4; }
 
+// crossattention key|value weight / bias offsets of a layer (imt_layer_desc.cross_kv_*)
+int64_t kv_w_off(const imt_stack_desc* m, const imt_layer_desc& p) { return p.cross_kv_w >= 0 ? p.cross_kv_w : p.cross_attn.qkv_w + (int64_t)m->d * m->d; }
+int64_t kv_b_off(const imt_stack_desc* m, const imt_layer_desc& p) { return p.cross_kv_b >= 0 ? p.cross_kv_b : p.cross_attn.qkv_b + m->d; }
+// all layers' key|value projections contiguous in layer order -> one [L*2d, d] weight: ONE GEMM projects the encoder
+// states for every layer (forward), one forms d(encoder states) and one the weight gradients (backward)
+bool cross_kv_batched(const imt_stack_desc* m) {
+  if (!m->is_decoder || m->n_layers < 2) return false;
+  const int64_t d = m->d;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const imt_layer_desc& p = m->layers[l];
+    if (p.cross_attn.qkv_w < 0 || p.cross_kv_w < 0 || p.cross_kv_b < 0) return false;
+    if (p.cross_kv_w != m->layers[0].cross_kv_w + (int64_t)l * 2 * d * d) return false;
+    if (p.cross_kv_b != m->layers[0].cross_kv_b + (int64_t)l * 2 * d) return false;
+  }
+  return true;
+}
+
 void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, LayerWs* layers) {
   Carver c(ws);
   const int64_t N = (int64_t)B * T, Nk = (int64_t)B * Tk, d = m->d, ff = m->ff, es = esize(m->dtype);
   w.emb_sum = c.take(N * d * es); w.emb_mean = (float*)c.take(N * 4); w.emb_rstd = (float*)c.take(N * 4);
   w.x0 = c.take(N * d * es);
   w.layers = layers;
+  const bool batched = cross_kv_batched(m);
+  const int64_t L2d = (int64_t)m->n_layers * 2 * d;
+  w.kv_all = w.d_kv_all = nullptr;
+  if (batched) { w.kv_all = c.take(Nk * L2d * es); w.d_kv_all = c.take(Nk * L2d * es); }
   for (int l = 0; l < m->n_layers; ++l) {
     LayerWs& L = layers[l];
     AttnWs& s = L.self_attn;
@@ -70,7 +93,9 @@ void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, 
     AttnWs& x = L.cross;
     memset(&x, 0, sizeof(x));
     if (m->is_decoder && m->layers[l].cross_attn.qkv_w >= 0) {
-      x.qkv = c.take(N * d * es); x.kv = c.take(Nk * 2 * d * es); x.ctx = c.take(N * d * es);
+      x.qkv = c.take(N * d * es); x.ctx = c.take(N * d * es);
+      if (batched) { x.kv = w.kv_all ? (void*)((char*)w.kv_all + (int64_t)l * 2 * d * es) : nullptr; x.kv_ld = L2d; }
+      else { x.kv = c.take(Nk * 2 * d * es); x.kv_ld = 2 * d; }
       x.lse = (float*)c.take((int64_t)B * m->heads * T * 4);
       x.pre_ln = c.take(N * d * es); x.mean = (float*)c.take(N * 4); x.rstd = (float*)c.take(N * 4);
       x.out = c.take(N * d * es);
@@ -170,7 +195,8 @@ inline char* offp(void* p, int64_t elems, int64_t es) { return reinterpret_cast<
 // ------------------------------------------------------------------------------------------------ forward
 // attention block (BertAttention = BertSelfAttention + BertSelfOutput); kv_src == nullptr -> self attention
 int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void* x, int B, int T, const void* kv_src, int Tk,
-                   const MaskSet& ms, bool training, uint64_t seed, int layer, int site0) {
+                   const MaskSet& ms, bool training, uint64_t seed, int layer, int site0, int64_t kv_w = -1, int64_t kv_b = -1,
+                   bool kv_ready = false) {
   const int d = c.m->d;
   const int N = B * T;
   const float hp = training ? c.m->hidden_dropout : 0.f, ap = training ? c.m->attn_dropout : 0.f;
@@ -182,8 +208,9 @@ int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void*
   } else {
     const int Nk = B * Tk;
     RC(linear_fwd(c, x, d, N, d, p.qkv_w, p.qkv_b, d, w.qkv, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
-    RC(linear_fwd(c, kv_src, d, Nk, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d, 2 * d, w.kv, 2 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
-    attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, 2 * d, offp(w.kv, d, c.es), 2 * d, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
+    if (!kv_ready)  // (batched: the key|value projections of all layers were formed by one GEMM before the layer loop)
+      RC(linear_fwd(c, kv_src, d, Nk, d, kv_w, kv_b, 2 * d, w.kv, w.kv_ld, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, w.kv_ld, offp(w.kv, d, c.es), w.kv_ld, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
   }
   RC(imt_attention_fwd(&a, c.st));
   RC(linear_fwd(c, w.ctx, d, N, d, p.o_w, p.o_b, d, w.pre_ln, d, x, d, nullptr, IMT_AUX_NONE, hp, site_seed(seed, layer, site0 + 1)));
@@ -195,7 +222,7 @@ int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void*
 // sw.d_run; cross: also d_kv_src (accumulate flag).  `slot` selects the dpre/ddrop scratch pair (1 cross, 2 self).
 int attn_block_bwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, StackWs& sw, DeferredDW& dw, int slot, const void* x, int B, int T,
                    const void* kv_src, int Tk, const MaskSet& ms, bool training, uint64_t seed, int layer, int site0, const void* dy,
-                   void* d_kv_src, int accumulate_kv) {
+                   void* d_kv_src, int accumulate_kv, int64_t kv_w = -1, int64_t kv_b = -1, void* d_kv_batched = nullptr) {
   const int d = c.m->d;
   const int N = B * T;
   const float hp = training ? c.m->hidden_dropout : 0.f, ap = training ? c.m->attn_dropout : 0.f;
@@ -217,16 +244,24 @@ int attn_block_bwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, StackWs& sw
     RC(linear_bwd_input(c, sw.d_qkv, 3 * d, N, 3 * d, p.qkv_w, d, sw.d_run, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
   } else {
     const int Nk = B * Tk;
-    attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, 2 * d, offp(w.kv, d, c.es), 2 * d, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
+    attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, w.kv_ld, offp(w.kv, d, c.es), w.kv_ld, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
     a.dO = sw.d_ctx; a.lddo = d;
-    a.dQ = sw.d_q; a.lddq = d; a.dK = sw.d_kv; a.lddk = 2 * d; a.dV = offp(sw.d_kv, d, c.es); a.lddv = 2 * d;
+    // batched key|value projections: dK|dV of this layer go to its column block of d_kv_all; d(encoder states) and the
+    // weight gradients of all layers are formed after the layer loop (imt_stack_backward)
+    void* dkv = d_kv_batched ? d_kv_batched : sw.d_kv;
+    const int64_t lddkv = d_kv_batched ? w.kv_ld : 2 * d;
+    a.dQ = sw.d_q; a.lddq = d; a.dK = dkv; a.lddk = lddkv; a.dV = offp(dkv, d, c.es); a.lddv = lddkv;
     a.delta = sw.delta;
     RC(imt_attention_bwd(&a, c.st));
     dw.add(c, sw.d_q, d, x, d, N, d, d, p.qkv_w, p.qkv_b);
-    dw.add(c, sw.d_kv, 2 * d, kv_src, d, Nk, 2 * d, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d);
     RC(linear_bwd_input(c, sw.d_q, d, N, d, p.qkv_w, d, sw.d_run, d, d_pre, d, nullptr, IMT_AUX_NONE, 0));
-    if (d_kv_src)
-      RC(linear_bwd_input(c, sw.d_kv, 2 * d, Nk, 2 * d, p.qkv_w + (int64_t)d * d, d, d_kv_src, d, nullptr, 0, nullptr, IMT_AUX_NONE, accumulate_kv));
+    // the key|value weight gradient stays in this layer's grouped launch either way (its 32 tiles fill CUs the other six
+    // products of a decoder layer leave idle; as a separate batched launch it cost +0.07 ms/step)
+    dw.add(c, dkv, lddkv, kv_src, d, Nk, 2 * d, d, kv_w, kv_b);
+    if (!d_kv_batched) {
+      if (d_kv_src)
+        RC(linear_bwd_input(c, sw.d_kv, 2 * d, Nk, 2 * d, kv_w, d, d_kv_src, d, nullptr, 0, nullptr, IMT_AUX_NONE, accumulate_kv));
+    }
   }
   return IMT_OK;
 }
@@ -297,13 +332,18 @@ extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io
   const void* x = x0;
   const MaskSet self_ms{io->key_mask, io->query_mask, io->mask3d, io->causal};
   const MaskSet cross_ms{io->enc_mask, nullptr, nullptr, 0};
+  const bool batched = cross_kv_batched(m);
+  if (batched)  // key|value projections of the encoder states for ALL layers: one [B*Tk, d] x [L*2d, d]^T product
+    RC(linear_fwd(c, io->enc_states, d, B * io->Tk, d, m->layers[0].cross_kv_w, m->layers[0].cross_kv_b, m->n_layers * 2 * d, w.kv_all,
+                  (int64_t)m->n_layers * 2 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
   for (int l = 0; l < m->n_layers; ++l) {
     const imt_layer_desc& p = m->layers[l];
     LayerWs& L = layers[l];
     RC(attn_block_fwd(c, p.self_attn, L.self_attn, x, B, T, nullptr, 0, self_ms, training, seed, l, 0));
     const void* a = L.self_attn.out;
     if (m->is_decoder && p.cross_attn.qkv_w >= 0) {
-      RC(attn_block_fwd(c, p.cross_attn, L.cross, a, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4));
+      RC(attn_block_fwd(c, p.cross_attn, L.cross, a, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4, kv_w_off(m, p),
+                        kv_b_off(m, p), batched));
       a = L.cross.out;
     }
     if (l == m->n_layers - 1) L.out = io->out;  // last LN writes straight into the caller's output
@@ -328,6 +368,7 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   // The running gradient w.r.t. the current layer's output lives in w.d_run between layers (and between segment
   // calls); the first segment reads it from io->d_out.
   const void* dy = (layer_hi == m->n_layers) ? io->d_out : w.d_run;
+  const bool batched = cross_kv_batched(m);
   DeferredDW dw;
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const imt_layer_desc& p = m->layers[l];
@@ -340,12 +381,21 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
     RC(ffn_bwd(c, p, L, w, dw, a_ffn_in, N, training, seed, l, dy));
     if (has_cross) {
       const bool first_cross = (l == m->n_layers - 1);
+      void* dkv_l = batched ? offp(w.d_kv_all, (int64_t)l * 2 * d, c.es) : nullptr;
       RC(attn_block_bwd(c, p.cross_attn, L.cross, w, dw, 1, a_self, B, T, io->enc_states, io->Tk, cross_ms, training, seed, l, 4, w.d_run,
-                        io->d_enc_states, first_cross ? 0 : 1));
+                        io->d_enc_states, first_cross ? 0 : 1, kv_w_off(m, p), kv_b_off(m, p), dkv_l));
     }
     RC(attn_block_bwd(c, p.self_attn, L.self_attn, w, dw, 2, x_in, B, T, nullptr, 0, self_ms, training, seed, l, 0, w.d_run, nullptr, 0));
     RC(dw.flush(c));  // all 4 (encoder) / 7 (decoder) weight-gradient GEMMs of this layer: one launch
     dy = w.d_run;
+  }
+  if (layer_lo == 0 && batched) {
+    // every layer has written its dK|dV block: d(encoder states) = d_kv_all [Nk, L*2d] x W_kv [L*2d, d], one product with
+    // K = L*2d instead of L accumulating ones
+    const int Nk = B * io->Tk;
+    const int L2d = m->n_layers * 2 * d;
+    if (io->d_enc_states)
+      RC(linear_bwd_input(c, w.d_kv_all, L2d, Nk, L2d, m->layers[0].cross_kv_w, d, io->d_enc_states, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0));
   }
   if (layer_lo == 0) {
     const void* dy0 = (m->n_layers == 0) ? io->d_out : dy;
@@ -415,8 +465,8 @@ extern "C" int imt_decode_begin(const imt_stack_desc* m, const void* enc_states,
   const int64_t per_layer = (int64_t)B * Tk * 2 * d;
   for (int l = 0; l < m->n_layers; ++l) {
     const imt_attn_block& p = m->layers[l].cross_attn;
-    RC(linear_fwd(c, enc_states, d, B * Tk, d, p.qkv_w + (int64_t)d * d, p.qkv_b + d, 2 * d, offp(cross_kv, l * per_layer, c.es), 2 * d,
-                  nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
+    RC(linear_fwd(c, enc_states, d, B * Tk, d, kv_w_off(m, m->layers[l]), kv_b_off(m, m->layers[l]), 2 * d,
+                  offp(cross_kv, l * per_layer, c.es), 2 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
   }
   return IMT_OK;
 }

@@ -54,8 +54,12 @@ class GradSync:
         for dec in decs:
             layers = list(dec.decoder.layer)
             for li, lyr in enumerate(layers):
-                ps = lyr.ordered_params(with_self_attention=id(lyr.attention) not in shared)
+                ps = lyr.ordered_params(with_self_attention=id(lyr.attention) not in shared, with_cross_key_value=False)
                 ms[(id(dec), li)] = end_of(ps)
+            # the grouped cross-attention key|value projections get their gradients in the layer-0 segment
+            kv = [p for lyr in layers for p in (lyr.crossattention.self.key.weight, lyr.crossattention.self.value.weight,
+                                                 lyr.crossattention.self.key.bias, lyr.crossattention.self.value.bias)]
+            ms[(id(dec), 0)] = max(ms.get((id(dec), 0), 0), end_of(kv))
             # embedding LN of the decoder becomes final with layer 0 (embedding backward runs in that segment)
             ms[(id(dec), 0)] = max(ms.get((id(dec), 0), 0),
                                    end_of([dec.embeddings.LayerNorm.weight, dec.embeddings.LayerNorm.bias]))

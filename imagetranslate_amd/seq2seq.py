@@ -204,8 +204,16 @@ class Seq2Seq(nn.Module):
         decs = list(self.decoder) if isinstance(self.decoder, nn.ModuleList) else [self.decoder]
         shared = {id(l.attention) for l in self.encoder.encoder.layer}
         for dec in decs:
-            for lyr in reversed(list(dec.decoder.layer)):
-                ps += lyr.ordered_params(with_self_attention=id(lyr.attention) not in shared)
+            layers = list(dec.decoder.layer)
+            for lyr in reversed(layers):
+                ps += lyr.ordered_params(with_self_attention=id(lyr.attention) not in shared, with_cross_key_value=False)
+            # the cross-attention key|value projections of ALL layers, contiguous in layer order ([L*2d, d] then [L*2d]):
+            # the runtime projects the encoder states for every layer with one GEMM (and one each for d(encoder states)
+            # and dW in backward); their gradients are final when the decoder's backward reaches layer 0
+            for lyr in layers:
+                ps += [lyr.crossattention.self.key.weight, lyr.crossattention.self.value.weight]
+            for lyr in layers:
+                ps += [lyr.crossattention.self.key.bias, lyr.crossattention.self.value.bias]
             ps += [dec.embeddings.LayerNorm.weight, dec.embeddings.LayerNorm.bias]
         for lyr in reversed(list(self.encoder.encoder.layer)):
             ps += lyr.ordered_params()

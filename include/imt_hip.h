@@ -239,6 +239,11 @@ typedef struct imt_layer_desc {
   int64_t ff1_w, ff1_b;      /* intermediate.dense [ff,d] */
   int64_t ff2_w, ff2_b;      /* output.dense [d,ff] */
   int64_t ln2_g, ln2_b;      /* output.LayerNorm */
+  int64_t cross_kv_w, cross_kv_b; /* crossattention key|value weight [2d,d] / bias [2d] when they do NOT follow the query
+                                     projection in the flat buffer (-1: they sit at cross_attn.qkv_w + d*d / qkv_b + d).
+                                     When these blocks of ALL layers are contiguous in layer order ([L*2d, d], [L*2d]),
+                                     the runtime projects the encoder states for every layer with ONE GEMM and forms
+                                     d(encoder states) / dW of all layers with one GEMM each. */
 } imt_layer_desc;
 
 typedef struct imt_stack_desc {
