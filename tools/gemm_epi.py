@@ -39,13 +39,14 @@ def case(name, lay, M, N, K, bias=False, aux=None, drop=0.0, resid=False):
         res.append("%6.1f us %4.0f TF" % (us, 2.0 * M * N * K / us / 1e6))
     print("%-34s dbuf %s | sbuf %s | ws %s" % (name, *res), flush=True)
 
-T, d, ff = 8192, 512, 2048
-case("ffn1 fwd plain        NT 2048x512", O.IMT_NT, T, ff, d)
-case("ffn1 fwd bias+GELU    NT 2048x512", O.IMT_NT, T, ff, d, bias=True, aux=O.IMT_AUX_GELU_FWD)
-case("ffn2 dx plain         NN 2048x512", O.IMT_NN, T, ff, d)
-case("ffn2 dx DGELU         NN 2048x512", O.IMT_NN, T, ff, d, aux=O.IMT_AUX_DGELU)
-case("attn-out plain        NT 512x512", O.IMT_NT, T, d, d)
-case("attn-out bias+drop+res NT 512x512", O.IMT_NT, T, d, d, bias=True, drop=0.1, resid=True)
-case("ffn2 fwd plain        NT 512x2048", O.IMT_NT, T, d, ff)
-case("ffn2 fwd bias+drop+res NT 512x2048", O.IMT_NT, T, d, ff, bias=True, drop=0.1, resid=True)
-case("qkv dx + resid        NN 512x1536", O.IMT_NN, T, d, 3 * d, resid=True)
+if __name__ == "__main__":
+    T, d, ff = 8192, 512, 2048
+    case("ffn1 fwd plain        NT 2048x512", O.IMT_NT, T, ff, d)
+    case("ffn1 fwd bias+GELU    NT 2048x512", O.IMT_NT, T, ff, d, bias=True, aux=O.IMT_AUX_GELU_FWD)
+    case("ffn2 dx plain         NN 2048x512", O.IMT_NN, T, ff, d)
+    case("ffn2 dx DGELU         NN 2048x512", O.IMT_NN, T, ff, d, aux=O.IMT_AUX_DGELU)
+    case("attn-out plain        NT 512x512", O.IMT_NT, T, d, d)
+    case("attn-out bias+drop+res NT 512x512", O.IMT_NT, T, d, d, bias=True, drop=0.1, resid=True)
+    case("ffn2 fwd plain        NT 512x2048", O.IMT_NT, T, d, ff)
+    case("ffn2 fwd bias+drop+res NT 512x2048", O.IMT_NT, T, d, ff, bias=True, drop=0.1, resid=True)
+    case("qkv dx + resid        NN 512x1536", O.IMT_NN, T, d, 3 * d, resid=True)
