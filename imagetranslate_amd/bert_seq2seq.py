@@ -242,7 +242,13 @@ class _Pretrained(nn.Module):
         ids = ids.to(dev).contiguous()
         type_ids = None if type_ids is None else type_ids.to(dev).contiguous()
         pos_ids = None if pos_ids is None else pos_ids.to(dev).contiguous()
-        u8 = lambda m: None if m is None else m.to(device=dev, dtype=torch.uint8).contiguous()
+        def u8(m):  # masks as bytes: a bool tensor already is one byte per element (reinterpret, no conversion kernel)
+            if m is None:
+                return None
+            m = m.to(device=dev)
+            if m.dtype == torch.bool:
+                return m.contiguous().view(torch.uint8)
+            return m.to(dtype=torch.uint8).contiguous()
         anchor = store.anchor() if torch.is_grad_enabled() else None
         # dropout seed of this forward (the backward regenerates the same masks from it); tests pin it
         fixed = getattr(self, "_imt_dropout_seed", None)
