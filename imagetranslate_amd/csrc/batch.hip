@@ -87,7 +87,56 @@ __global__ __launch_bounds__(256) void mass_unmask_kernel(int64_t* text, const u
     if (mask[(int64_t)row * width + c]) text[(int64_t)row * width + c] = originals[row_offsets[row] + (c - first)];
 }
 
+// Non-pad target selection (src/seq2seq.py:175-177, train_image_mt.py:253-256): flat positions p = b*T1 + t of the
+// positions whose mask[b, col0 + t] is set, in order, plus the target ids at those positions and their count.  One
+// workgroup walks the B*T1 flags in chunks of 1024 with a running offset (ballot + popcount scan per wave, 16 wave
+// totals through LDS): ~5 us at 8128 positions instead of ~90 us of nonzero / boolean-index kernels.
+__global__ __launch_bounds__(1024) void select_plan_kernel(const uint8_t* __restrict__ mask, int64_t ld_mask,
+                                                           const int64_t* __restrict__ ids, int64_t ld_ids, int B, int T1, int col0,
+                                                           int32_t* __restrict__ idx, int64_t* __restrict__ targets,
+                                                           int32_t* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = B * T1;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < n; p0 += 1024) {
+    const int p = p0 + tid;
+    const int b = p / T1, t = p - b * T1;
+    const bool sel = (p < n) && mask[(int64_t)b * ld_mask + col0 + t] != 0;
+    const unsigned long long bal = __ballot(sel);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < wv; ++k) off += wave_tot[k];
+    if (sel) {
+      idx[off + before] = p;
+      targets[off + before] = ids[(int64_t)b * ld_ids + col0 + t];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = s_base;
+      for (int k = 0; k < 16; ++k) tot += wave_tot[k];
+      s_base = tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) count[0] = s_base;
+}
+
 }  // namespace
+
+extern "C" int imt_select_plan(const uint8_t* mask, int64_t ld_mask, const int64_t* ids, int64_t ld_ids, int B, int T1, int col0,
+                               int32_t* idx, int64_t* targets, int32_t* count, void* stream) {
+  IMT_CHECK_ARG(mask && ids && idx && targets && count && B > 0 && T1 >= 0 && col0 >= 0, "select_plan: bad args");
+  IMT_CHECK_ARG((int64_t)B * T1 < (1ll << 31), "select_plan: too many positions");
+  hipLaunchKernelGGL(select_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, ld_mask, ids, ld_ids, B, T1, col0, idx,
+                     targets, count);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
 
 extern "C" int imt_mass_mask(const imt_mass_args* a, void* stream) {
   IMT_CHECK_ARG(a, "mass_mask: null args");

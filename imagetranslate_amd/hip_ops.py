@@ -318,3 +318,24 @@ def attention_decode(q, k_base, v_base, n_keys, heads, *, ld_row, ld_pos, rep=1,
 
 def beam_step(args: "L.BeamArgs"):
     L.check(L.load().imt_beam_step(ctypes.byref(args), _stream()), "imt_beam_step")
+
+
+def select_plan(mask, ids, col0: int = 1):
+    """(idx int32 [n], targets int64 [n]) of the positions with mask[b, col0 + t] set; ONE small kernel + one 4-byte
+    device->host read (the row count shapes everything downstream, so this is the step's only synchronisation)."""
+    _req_cuda(mask, ids)
+    B, T = ids.shape
+    T1 = T - col0
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8) if mask.is_contiguous() else mask.contiguous().view(torch.uint8)
+    assert mask.dtype == torch.uint8 and mask.stride(1) == 1 and ids.stride(1) == 1 and ids.dtype == torch.int64
+    n = B * max(T1, 0)
+    idx = torch.empty(max(n, 1), dtype=torch.int32, device=ids.device)
+    targets = torch.empty(max(n, 1), dtype=torch.int64, device=ids.device)
+    count = torch.empty(1, dtype=torch.int32, device=ids.device)
+    if n == 0:
+        return idx[:0], targets[:0]
+    L.check(L.load().imt_select_plan(_p(mask), mask.stride(0), _p(ids), ids.stride(0), B, T1, col0, _p(idx), _p(targets), _p(count),
+                                     _stream()), "imt_select_plan")
+    k = int(count.item())
+    return idx[:k], targets[:k]

@@ -61,7 +61,9 @@ class _SelectRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        dx = torch.zeros((ctx.rows, dout.shape[1]), device=dout.device, dtype=dout.dtype)
+        # every row selected (no padding): the scatter writes all of dx, no zero fill needed
+        alloc = torch.empty if idx.numel() == ctx.rows else torch.zeros
+        dx = alloc((ctx.rows, dout.shape[1]), device=dout.device, dtype=dout.dtype)
         O.scatter_rows(dout.contiguous(), idx, dx)
         return dx, None
 
@@ -300,6 +302,8 @@ class Seq2Seq(nn.Module):
         """(row indices, targets) of the non-pad target positions (src/seq2seq.py:175-177, train_image_mt.py:253-256).
         The row count is data dependent, so this is the step's ONE host synchronisation; the fast path calls it before
         anything is enqueued so that it waits on nothing and the rest of the step is launched without bubbles."""
+        if tgt_mask.is_cuda and tgt_inputs.is_cuda and tgt_inputs.dtype == torch.int64 and tgt_mask.dtype in (torch.bool, torch.uint8):
+            return O.select_plan(tgt_mask, tgt_inputs, col0=1)
         idx = torch.nonzero(tgt_mask[:, 1:].reshape(-1), as_tuple=False).view(-1)
         return idx.to(torch.int32), tgt_inputs[:, 1:].reshape(-1)[idx]
 

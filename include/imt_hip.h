@@ -400,6 +400,12 @@ int imt_mass_mask(const imt_mass_args* a, void* stream);
 int imt_mass_unmask(int64_t* src_text, const uint8_t* src_mask, const int64_t* originals, const int64_t* row_offsets,
                     int n_rows, int width, void* stream);
 
+/* Non-pad target selection (src/seq2seq.py:175-177 `flat[tgt_mask[:, 1:]]`, train_image_mt.py:253-256 targets):
+ * idx[k] = flat position b*T1 + t of the k-th set mask[b, col0 + t] (row-major order), targets[k] = ids[b, col0 + t],
+ * count[0] = number selected.  idx / targets need room for B*T1 entries. */
+int imt_select_plan(const uint8_t* mask, int64_t ld_mask, const int64_t* ids, int64_t ld_ids, int B, int T1, int col0,
+                    int32_t* idx, int64_t* targets, int32_t* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,3 +55,20 @@ def test_mass_mask_device_statistics(cuda):
     assert abs(frac_mask - 0.8) < 0.01 and abs(frac_same - 0.1) < 0.01
     rnd = masked_new[(masked_new != 3) & (masked_new != masked_old)]
     assert int(rnd.min()) >= len(tp.special_tokens) and int(rnd.max()) < 500
+
+
+@pytest.mark.parametrize("B,T,p", [(64, 128, 1.0), (64, 128, 0.7), (3, 5, 0.5), (1, 2, 1.0), (7, 300, 0.0), (40, 129, 0.93)])
+def test_select_plan_matches_boolean_indexing(cuda, B, T, p):
+    """imt_select_plan == (nonzero(mask[:, 1:]), ids[:, 1:][mask[:, 1:]]) of src/seq2seq.py:175-177 -- bit-exact."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    ids = torch.randint(0, 30000, (B, T), generator=g)
+    mask = torch.rand(B, T, generator=g) < p
+    idx, tg = O.select_plan(mask.cuda(), ids.cuda(), col0=1)
+    exp_idx = torch.nonzero(mask[:, 1:].reshape(-1)).view(-1)
+    assert idx.dtype == torch.int32 and torch.equal(idx.cpu().long(), exp_idx)
+    assert torch.equal(tg.cpu(), ids[:, 1:][mask[:, 1:]])
+    # uint8 mask and a strided (sliced) ids view
+    wide = torch.randint(0, 30000, (B, T + 3), generator=g)
+    idx2, tg2 = O.select_plan(mask.to(torch.uint8).cuda(), wide.cuda()[:, :T], col0=1)
+    assert torch.equal(idx2.cpu().long(), exp_idx) and torch.equal(tg2.cpu(), wide[:, :T][:, 1:][mask[:, 1:]])
