@@ -212,7 +212,30 @@ __global__ __launch_bounds__(256) void xent_fused_lds_kernel(bf16_t* __restrict_
     z[c] = (bf16_t)(gs * (__expf((float)zs[c] - lse) - sm - ((c == t) ? (1.f - eps) : 0.f)));
 }
 
+// out[0] = scale * sum(x[0..n)) in a fixed order (one workgroup; the per-row losses of a step are a few thousand floats)
+__global__ __launch_bounds__(1024) void scaled_sum_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k];
+    out[0] = t * scale;
+  }
+}
+
 }  // namespace
+
+extern "C" int imt_scaled_sum(const float* x, int n, float scale, float* out, void* stream) {
+  IMT_CHECK_ARG(x && out && n >= 0, "scaled_sum: bad args");
+  hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, scale, out);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
 
 extern "C" int imt_log_softmax_fwd(int dtype, const void* logits, int64_t ld, float* lp, int64_t ldlp, float* lse, int N,
                                    int V, void* stream) {

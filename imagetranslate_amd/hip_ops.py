@@ -264,6 +264,14 @@ def xent_fused_fwd_bwd(logits, target, epsilon, ignore_index, grad_scale):
     return loss
 
 
+def scaled_sum(x, scale: float):
+    """scale * x.sum() as a 0-d fp32 tensor (one small deterministic kernel)."""
+    _req_cuda(x)
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    L.check(L.load().imt_scaled_sum(_p(x), x.numel(), float(scale), _p(out), _stream()), "imt_scaled_sum")
+    return out
+
+
 def sumsq(g, out, ws=None):
     _req_cuda(g, out, ws)
     if ws is None:

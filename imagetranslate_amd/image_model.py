@@ -148,7 +148,7 @@ class ImageCaptioning(ImageMassSeq2Seq):
         tgt_inputs = tgt_inputs.to(device)
         tgt_mask = tgt_mask.to(device)
         batch_lang = int(tgt_langs[0])
-        tgt_langs_t = tgt_langs.unsqueeze(-1).expand(-1, tgt_inputs.size(-1)).to(device)
+        tgt_langs_t = self._lang_grid(tgt_langs, tgt_inputs.size(-1), device)
         pos = tgt_positions[:, :-1].to(device) if tgt_positions is not None else None
         rows = self._decode(image_embeddings, u(src_pads), tgt_inputs, tgt_mask, tgt_langs_t, batch_lang,
                             position_ids=pos, proposals=proposals, pad_idx=pad_idx)

@@ -23,10 +23,10 @@ class MassSeq2Seq(Seq2Seq):
         src_inputs = src_inputs.to(device)
         src_pads = src_inputs != pad_idx
         tgt_mask = tgt_inputs != pad_idx
-        src_langs_t = src_langs.unsqueeze(-1).expand(-1, src_inputs.size(-1)).to(device)
+        src_langs_t = self._lang_grid(src_langs, src_inputs.size(-1), device)
         batch_lang = int(src_langs[0])
         encoder_states = self.encode(src_inputs, src_pads, src_langs_t)[0]
-        tgt_langs = src_langs.unsqueeze(-1).expand(-1, tgt_inputs.size(-1)).to(device)
+        tgt_langs = self._lang_grid(src_langs, tgt_inputs.size(-1), device)
         pos = tgt_positions[:, :-1].to(device) if tgt_positions is not None else None
         rows = self._decode(encoder_states, src_pads, tgt_inputs, tgt_mask, tgt_langs, batch_lang, position_ids=pos,
                             proposals=proposals, pad_idx=pad_idx)

@@ -88,7 +88,7 @@ class _FusedXentFn(torch.autograd.Function):
         rows = O.xent_fused_fwd_bwd(logits, targets, epsilon, ignore_index, 1.0 / max(n, 1))  # logits <- dlogits
         ctx.store, ctx.wo, ctx.bo, ctx.shape = store, wo, bo, (V, K)
         ctx.save_for_backward(x, w, logits)
-        return rows.sum() / max(n, 1)
+        return O.scaled_sum(rows, 1.0 / max(n, 1))
 
     @staticmethod
     def backward(ctx, g):
@@ -297,6 +297,29 @@ class Seq2Seq(nn.Module):
         return self.lexical_layer_norm(combined).to(dt)
 
     # shared tail of every forward variant: decoder -> non-pad row select -> vocabulary projection
+    def _uniform_grid(self, n_rows, width, value, device):
+        cache = self.__dict__.setdefault("_imt_lang_grids", {})
+        key = (int(n_rows), int(width), int(value), str(device))
+        grid = cache.get(key)
+        if grid is None:
+            if len(cache) > 256:
+                cache.clear()
+                self.__dict__["_imt_grid_info"] = {}
+            grid = torch.full((int(n_rows), int(width)), int(value), dtype=torch.int64, device=device)
+            cache[key] = grid
+            self.__dict__.setdefault("_imt_grid_info", {})[id(grid)] = (int(n_rows), int(value))
+        return grid
+
+    def _lang_grid(self, langs, width, device):
+        """Per-row language ids [B] -> token-type ids [B, width] on the device (src/seq2seq.py:151-152).  Batches are built
+        per language pair, so the ids are almost always uniform: that grid is kept on the device and reused (no expand +
+        host->device copy + contiguous copy per step)."""
+        if not langs.is_cuda and langs.numel() > 0:
+            lo, hi = int(langs.min()), int(langs.max())
+            if lo == hi:
+                return self._uniform_grid(langs.numel(), width, lo, device)
+        return langs.unsqueeze(-1).expand(-1, width).to(device)
+
     @staticmethod
     def _selection(tgt_inputs, tgt_mask):
         """(row indices, targets) of the non-pad target positions (src/seq2seq.py:175-177, train_image_mt.py:253-256).
@@ -310,9 +333,14 @@ class Seq2Seq(nn.Module):
     def _decode(self, encoder_states, enc_mask, tgt_inputs, tgt_mask, tgt_langs_t, batch_lang, position_ids=None,
                 proposals=None, pad_idx=0, sel_idx=None):
         decoder = self.decoder if not self.lang_dec else self.decoder[batch_lang]
+        info = self.__dict__.get("_imt_grid_info", {}).get(id(tgt_langs_t))
+        if info is not None:  # a cached uniform grid: use the (T-1)-wide one instead of a non-contiguous slice
+            types = self._uniform_grid(info[0], tgt_langs_t.size(1) - 1, info[1], tgt_langs_t.device)
+        else:
+            types = tgt_langs_t[:, :-1]
         decoder_output = decoder(encoder_states=encoder_states, input_ids=tgt_inputs[:, :-1],
                                  encoder_attention_mask=enc_mask, tgt_query_mask=tgt_mask[:, :-1],
-                                 position_ids=position_ids, token_type_ids=tgt_langs_t[:, :-1])
+                                 position_ids=position_ids, token_type_ids=types)
         if self.use_proposals:
             decoder_output = self.attend_proposal(decoder_output, proposals, pad_idx)
         flat = decoder_output.reshape(-1, decoder_output.size(-1))
@@ -351,8 +379,8 @@ class Seq2Seq(nn.Module):
         Returns (loss, ntokens)."""
         device = self.encoder.embeddings.word_embeddings.weight.device
         batch_lang = int(tgt_langs[0])
-        src_langs_t = src_langs.unsqueeze(-1).expand(-1, src_inputs.size(-1)).to(device)
-        tgt_langs_t = tgt_langs.unsqueeze(-1).expand(-1, tgt_inputs.size(-1)).to(device)
+        src_langs_t = self._lang_grid(src_langs, src_inputs.size(-1), device)
+        tgt_langs_t = self._lang_grid(tgt_langs, tgt_inputs.size(-1), device)
         src_inputs, tgt_inputs = src_inputs.to(device), tgt_inputs.to(device)
         src_mask, tgt_mask = src_mask.to(device), tgt_mask.to(device)
         sel_idx, targets = self._selection(tgt_inputs, tgt_mask)

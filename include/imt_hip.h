@@ -197,6 +197,8 @@ int imt_smoothed_nll_bwd(const float* dloss, const int64_t* target, float* dlp, 
                          float epsilon, int64_t ignore_index, void* stream);
 int imt_xent_fused_fwd_bwd(int dtype, void* logits, int64_t ld, const int64_t* target, float* loss_rows, int N,
                            int V, float epsilon, int64_t ignore_index, float grad_scale, void* stream);
+/* out[0] = scale * sum(x[0..n)), fixed summation order: the `.mean()` of the per-row losses (train_image_mt.py:282). */
+int imt_scaled_sum(const float* x, int n, float scale, float* out, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * (clip_grad_norm_ train_image_mt.py:291 ; AdamInverseSqrtWithWarmup src/utils.py:105-156)
