@@ -173,6 +173,7 @@ SIGNATURES = {
                               c_int64, c_int, _P]),
     "imt_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
     "imt_gated_mix": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "imt_debug_spin": (c_int, [c_int, c_int, c_int, c_int64, _P]),
     "imt_prof_enable": (c_int, [c_int]),
     "imt_prof_report": (c_int, [POINTER(ProfRow), c_int]),
     "imt_stack_workspace_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int, c_int]),

@@ -96,3 +96,22 @@ extern "C" int imt_prof_report(imt_prof_row* rows, int max_kinds) {
   g_pool_next = 0;
   return n;
 }
+
+// ------------------------------------------------------------------------------------------------ test utility
+// Occupies `blocks` workgroups (threads, lds_bytes each) for ~`cycles` shader clocks: stands in for a long-running
+// communication kernel when measuring how the step's kernels behave with fewer free CUs (tools/comm_pressure.py).
+namespace {
+__global__ void spin_kernel(long long cycles, int lds_bytes) {
+  extern __shared__ char spin_lds[];
+  if (lds_bytes > 0 && threadIdx.x == 0) spin_lds[0] = 1;
+  const long long t0 = clock64();
+  while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+extern "C" int imt_debug_spin(int blocks, int threads, int lds_bytes, int64_t cycles, void* stream) {
+  IMT_CHECK_ARG(blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 65536 && cycles >= 0, "debug_spin: bad args");
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, (long long)cycles, lds_bytes);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}

@@ -11,7 +11,7 @@
 // Five main loops share the tile product (compute_tile) and the LDS-restaged epilogue; imt_gemm picks one per shape
 // from measurements (profiles/r01_v5_gemm_shapes.txt, profiles/r01_gemm_epilogue_study.txt):
 //   gemm_ws_kernel         : persistent, wave-specialised -- 4 MFMA waves + 4 LDS-DMA producer waves (buffer_load ... lds,
-//                            16 B/lane, swizzle on the SOURCE address, 4-stage ring, one raw s_barrier per K tile, counted
+//                            16 B/lane, swizzle on the SOURCE address, 3-stage ring, one raw s_barrier per K tile, counted
 //                            vmcnt on the producers); on a workgroup's last tile the idle producers share the epilogue.
 //                            K a whole number of tiles and (<= one tile per CU or K >= 1024).
 //   gemm_grouped_tn_kernel : the same split for ALL weight-gradient products of a layer in one launch (full K per tile,
@@ -494,12 +494,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict
 
 // ------------------------------------------------------------------------------------------------ persistent wave-specialised kernel
 // The main GEMM loop of the path when K is a whole number of tiles: 512 threads, waves 0-3 multiply (64x64 each),
-// waves 4-7 stream the operand tiles by LDS-DMA into a 4-stage ring and run AHEAD ACROSS OUTPUT TILES (one workgroup
+// waves 4-7 stream the operand tiles by LDS-DMA into a 3-stage ring and run AHEAD ACROSS OUTPUT TILES (one workgroup
 // per CU walks tiles b, b+grid, ...), so neither the DMA issue cost nor the first-tile latency nor the epilogue of a
-// tile stalls the MFMA waves of the next one.  The epilogue restages through its own 32 KiB (ring 128 KiB + 32 KiB
-// = the CU's whole 160 KiB).  Producers keep their own counted vmcnt (only DMA), consumers' epilogue loads/stores
+// tile stalls the MFMA waves of the next one.  The epilogue restages through its own 32 KiB (ring 96 KiB + 32 KiB
+// = 128 KiB: a communication workgroup of a data-parallel job can share the CU).  Producers keep their own counted vmcnt (only DMA), consumers' epilogue loads/stores
 // have theirs; the only coupling is one raw s_barrier per K tile plus the epilogue's four.
-constexpr int WS_NST = 4;
+constexpr int WS_NST = 3;   // 96 KiB ring + 32 KiB epilogue staging = 128 KiB: leaves LDS for a co-resident communication workgroup
 constexpr int WS_THREADS = 512;
 constexpr int WS_LDS = WS_NST * STAGE_BYTES + 32768;
 

@@ -46,6 +46,9 @@ typedef struct imt_prof_row {
   double flops;
   double bytes;
 } imt_prof_row;
+/* test utility: `blocks` workgroups of `threads` threads holding `lds_bytes` of LDS each spin for ~`cycles` shader clocks
+ * (a stand-in for a long-running communication kernel when measuring the step under CU pressure). */
+int imt_debug_spin(int blocks, int threads, int lds_bytes, int64_t cycles, void* stream);
 int imt_prof_enable(int on);
 int imt_prof_report(imt_prof_row* rows, int max_kinds);
 
