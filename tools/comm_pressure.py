@@ -36,3 +36,26 @@ print("undisturbed: %.3f ms/step" % base, flush=True)
 for blocks in (8, 16, 32, 64):
     ms = run(blocks)
     print("%3d workgroups held on a side stream (256 threads, 4 KiB LDS): %.3f ms/step (%+.1f%%)" % (blocks, ms, 100 * (ms / base - 1)), flush=True)
+
+# per-kernel view: which kinds lose time with 32 workgroups held
+def kinds(blocks):
+    for _ in range(3): train_step(model, opt, batch)
+    torch.cuda.synchronize()
+    lib.imt_prof_enable(1)
+    for _ in range(3):
+        if blocks:
+            side.wait_stream(torch.cuda.current_stream())
+            L.check(lib.imt_debug_spin(blocks, 256, 4096, int(6e-3 * 2.1e9), ctypes.c_void_p(side.cuda_stream)), "spin")
+        train_step(model, opt, batch)
+        if blocks:
+            torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    rows = (L.ProfRow * 256)()
+    n = lib.imt_prof_report(rows, 256)
+    lib.imt_prof_enable(0)
+    return {rows[i].kind.decode(): rows[i].total_ms / 3 for i in range(n)}
+
+a, b = kinds(0), kinds(32)
+print("%-28s %9s %9s" % ("kind", "free", "32 held"))
+for k in sorted(a, key=lambda k: -(b.get(k, 0) - a[k])):
+    print("%-28s %9.3f %9.3f  %+.3f" % (k, a[k], b.get(k, 0.0), b.get(k, 0.0) - a[k]))
