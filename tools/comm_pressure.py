@@ -33,10 +33,13 @@ def run(blocks, threads=256, lds=4096, steps=20):
 
 base = run(0)
 print("undisturbed: %.3f ms/step" % base, flush=True)
-for blocks in (8, 16, 32, 64):
-    ms = run(blocks)
-    print("%3d workgroups held on a side stream (256 threads, 4 KiB LDS): %.3f ms/step (%+.1f%%)" % (blocks, ms, 100 * (ms / base - 1)), flush=True)
+for blocks, threads, lds in ((8, 256, 4096), (32, 256, 4096), (64, 256, 4096), (32, 512, 32768), (64, 512, 32768), (32, 512, 49152)):
+    ms = run(blocks, threads, lds)
+    print("%3d workgroups held on a side stream (%d threads, %d KiB LDS): %.3f ms/step (%+.1f%%)" %
+          (blocks, threads, lds // 1024, ms, 100 * (ms / base - 1)), flush=True)
 
+if os.environ.get("IMT_COMM_KINDS") != "1":
+    raise SystemExit(0)
 # per-kernel view: which kinds lose time with 32 workgroups held
 def kinds(blocks):
     for _ in range(3): train_step(model, opt, batch)
