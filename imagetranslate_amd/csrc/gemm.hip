@@ -828,6 +828,10 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
     if (pipe_ok && splits == 1 && (tiles <= 256 || a->K >= 1024)) variant = 5;
     else variant = (a->layout == IMT_TN) ? 1 : 3;
+    // data-parallel knob (off by default): when a collective's kernels hold some CUs, a persistent
+    // launch of exactly one tile per CU needs a full second round; three small workgroups per CU degrade gracefully
+    static const bool prefer_small = getenv("IMT_GEMM_SHARE_CUS") != nullptr;
+    if (prefer_small && variant == 5 && a->layout != IMT_TN && tiles > 192 && tiles <= 256 && a->K < 1024) variant = 3;
   }
   if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;
   if (variant == 5 && (!pipe_ok || splits > 1)) variant = 3;
