@@ -307,7 +307,10 @@ class _StackFn(torch.autograd.Function):
         L.check(lib.imt_stack_forward(ctypes.byref(desc), ctypes.byref(io), ctypes.c_void_p(ws.data_ptr()), ws_bytes, st),
                 "imt_stack_forward")
         ctx.mod, ctx.store, ctx.dtype, ctx.io, ctx.ws, ctx.ws_bytes = mod, store, dtype, io, ws, ws_bytes
-        ctx.keep = (ids, type_ids, pos_ids, key_mask, query_mask, mask3d, enc_mask, enc_states, out, params)
+        ctx.keep = (ids, type_ids, pos_ids, key_mask, query_mask, mask3d, enc_mask, enc_states, params)
+        # the output goes through save_for_backward: held as a plain attribute it would close a reference cycle
+        # (out -> grad_fn -> ctx -> out) that only the cyclic collector frees, ~B*T*d bytes per step until then
+        ctx.save_for_backward(out)
         ctx.layout_version = store.layout_version
         ctx.is_decoder = bool(desc.is_decoder)
         return out
@@ -320,6 +323,8 @@ class _StackFn(torch.autograd.Function):
         desc, _keep = mod._desc(store, dtype)
         desc.params = ctx.keep[-1].data_ptr()
         desc.grads = store.grad.data_ptr()
+        (out,) = ctx.saved_tensors
+        io.out = out.data_ptr()
         d_out = d_out.to(dtype).contiguous()
         io.d_out = d_out.data_ptr()
         d_enc = None
@@ -344,7 +349,7 @@ class _StackFn(torch.autograd.Function):
                 L.check(lib.imt_stack_backward(ctypes.byref(desc), ctypes.byref(io), ctypes.c_void_p(ctx.ws.data_ptr()),
                                                ctx.ws_bytes, 0, 0, st), "imt_stack_backward")
         store.attach_grad_views()
-        ctx.ws = None
+        ctx.ws = ctx.keep = None
         return (None, d_enc) + (None,) * 13
 
 

@@ -276,6 +276,32 @@ def test_overlapped_optimizer_step_matches_in_order_step(cuda, dtype):
         assert diff <= 2e-5 * max(1.0, float(v.float().abs().max())), (k, diff)  # atomics-order noise is ~3e-6 after 4 steps
 
 
+def test_train_steps_retain_no_memory_without_the_cyclic_collector(cuda):
+    """With gc disabled, device memory held between steps must not grow: an autograd node that keeps its own output
+    as a plain attribute forms a cycle only the cyclic collector frees (a B*T*d leak per step until it runs)."""
+    import gc
+    from imagetranslate_amd.utils import AdamInverseSqrtWithWarmup
+    _, ours = _pair()
+    ours.set_compute_dtype(torch.bfloat16)
+    ours.train()
+    opt = AdamInverseSqrtWithWarmup(ours.parameters(), lr=1e-3, betas=(0.9, 0.98), warmup_updates=2)
+    b = _toy_batch(seed=7)
+    held = []
+    gc.collect()
+    gc.disable()
+    try:
+        for step in range(12):
+            loss, _ = ours.loss_fused(b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
+            loss.backward()
+            opt.step(max_grad_norm=1.0, zero_grad=True, overlap_next_forward=True)
+            del loss
+            torch.cuda.synchronize()
+            held.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert held[-1] == held[3], held
+
+
 @pytest.mark.parametrize("B,S,T", [(2, 512, 512), (1, 1, 2), (3, 7, 2), (2, 130, 129)])
 def test_extreme_lengths_fp32_parity(cuda, B, S, T):
     """Maximum length (max_position_embeddings = 512: multi-tile attention, two-kernel backward), the shortest legal
