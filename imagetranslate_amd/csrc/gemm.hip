@@ -113,6 +113,7 @@ struct EpiParams {
   float inv_keep; uint32_t drop_thresh; uint64_t seed;
   float* a_colsum;  // TN only: a_colsum[m] += alpha * sum_k A[k][m]   (bias gradient fused into the dW GEMM)
   int dbg;          // tuning only (tools/gemm_shapes.py): bit0 skip the tile products, bit1 skip the in-loop DMA
+  unsigned long long* trace;  // tuning only (IMT_GEMM_TRACE=1): per-workgroup phase time stamps of the 256-tile kernel
 };
 
 // ------------------------------------------------------------------------------------------------ tile product
@@ -184,89 +185,131 @@ template <typename T> struct ColSum {
 // directly they would touch 16 rows x 32 bytes per instruction.  Instead the block restages its tile through LDS in
 // two passes of 64 rows (fp32, 32 KiB, 16-byte groups XOR-swizzled by row) so that EVERY global access of the epilogue
 // (bias, residual, GELU aux, C) is a 16-B-per-lane (8 B for bf16 stores) access with 32 consecutive lanes per row.
+IMT_DEVICE void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 IMT_DEVICE int epi_off(int row, int c4) { return row * 512 + ((c4 ^ (row & 31)) << 4); }
 
 // NTHR threads share the group loop (256 = the MFMA waves alone; 512 = the persistent kernel's LAST tile, where its idle
 // producer waves help: HAS_ACC = false for them -- they hold no accumulators and only join from the first barrier on).
-template <typename T, int NTHR = NTHREADS, bool HAS_ACC = true>
-IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
-                         float alpha, bool active = true) {
+// WROWS = 128 (the 256 x 256 kernel): an owning wave holds all 128 rows of the tile's 64-column strip, acc[8][4], and
+// restages rows 64*pass .. +63 in each pass instead of sitting one out.
+//
+// CODE SIZE is a first-order cost here: the group loop is unrolled (4-8 bodies per pass), and a body that branches over
+// every option at run time (GELU, GELU', dropout, residual, fp32 / accumulate, ragged-N scalar tail) is > 1000
+// instructions of which a launch executes a few dozen -- the wave then takes an instruction-cache miss at every
+// skipped block (measured with IMT_GEMM_TRACE on the 256-tile kernel: 12-18 us per tile for what is 3 us of work).
+// So the epilogue KIND is resolved once per tile (uniform) into a straight-line template instance for the kinds the
+// train step uses on full tiles; everything else (edge tiles, split-K atomics, rare combinations) runs ONE rolled,
+// fully general body.
+enum { EM_PLAIN = 0, EM_RESID, EM_DROP_RESID, EM_GELU, EM_DGELU, EM_F32, EM_F32_ACC, EM_ACC, EM_GENERIC };
+
+IMT_DEVICE int epi_kind(const EpiParams& ep) {
+  const bool extras = ep.resid || ep.drop_thresh;
+  if (ep.atomic) return EM_GENERIC;
+  if (ep.c_f32) return (ep.aux_mode != IMT_AUX_NONE || extras) ? EM_GENERIC : (ep.accumulate ? EM_F32_ACC : EM_F32);
+  if (ep.accumulate) return (ep.aux_mode != IMT_AUX_NONE || extras) ? EM_GENERIC : EM_ACC;
+  if (ep.aux_mode == IMT_AUX_GELU_FWD) return extras ? EM_GENERIC : EM_GELU;
+  if (ep.aux_mode == IMT_AUX_DGELU) return extras ? EM_GENERIC : EM_DGELU;
+  if (ep.drop_thresh) return ep.resid ? EM_DROP_RESID : EM_GENERIC;
+  return ep.resid ? EM_RESID : EM_PLAIN;
+}
+
+// restage this wave's part of rows 64*pass .. +63 (fp32, swizzled); between the two LDS-only barriers.  __syncthreads()
+// would also drain vmcnt, i.e. make every pass wait for the previous pass's global stores to be acknowledged.
+template <bool HAS_ACC, int WROWS>
+IMT_DEVICE void epi_restage(const f32x4 (*acc)[4], char* smem, int pass, int wm, int wn, float alpha) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  lds_barrier();  // previous users of smem (K loop / previous pass) are done
+  if (HAS_ACC && (WROWS == 128 || wm == 64 * pass)) {
+    const int ib = (WROWS == 128) ? 4 * pass : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(smem + epi_off(16 * i + lr, (wn + 16 * j + 4 * lg) >> 2)) = acc[ib + i][j] * alpha;
+  }
+  lds_barrier();
+}
+
+// full tile, kind known at compile time: no bounds checks, no branches; the per-element operands of a pass (GELU' input,
+// residual, old C) are requested before the tile is restaged and stay in flight across the two barriers
+template <typename T, int KIND, int NTHR, bool HAS_ACC, int WROWS>
+IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int N, const EpiParams& ep, float alpha) {
+  typedef typename Vec4<T>::type raw_t;
+  constexpr int GPT = 2048 / NTHR;  // 4-column groups per thread per 64-row pass
+  constexpr bool C32 = (KIND == EM_F32 || KIND == EM_F32_ACC);
+  const int c4 = threadIdx.x & 31, n = n0 + 4 * c4;
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* resid = reinterpret_cast<const T*>(ep.resid);
   T* aux = reinterpret_cast<T*>(ep.aux);
-  // bf16: the aux (GELU') / residual / bias operands of a pass are requested BEFORE the tile is restaged through LDS, as
-  // raw 8-byte loads that stay in flight across the two barriers (converted only where used); read inside the group
-  // loop each would be a dependent global-load latency per group (tools/gemm_epi.py: +24 us on 8192x2048x512).
-  typedef typename Vec4<T>::type raw_t;
-  constexpr bool PREFETCH = (sizeof(T) == 2);
+  const f32x4 bv = bias ? Vec4<T>::load(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    constexpr int GPT = 2048 / NTHR;  // 4-column groups per thread per 64-row pass
-    raw_t zr[GPT], rr[GPT], br = raw_t{};
-    const bool pre = PREFETCH && active && !ep.atomic && (m0 + 64 * pass + 64 <= M) && (n0 + BN <= N);
-    // fp32 C += ... (weight gradients): the old C values are requested up front as well (8-wave epilogues only, where 4
-    // groups per thread keep it at 16 registers)
-    constexpr bool PREFETCH_C = (NTHR == 512);
-    f32x4 cr[PREFETCH_C ? GPT : 1];
-    const bool pre_c = PREFETCH_C && active && !ep.atomic && ep.accumulate && ep.c_f32 && (m0 + 64 * pass + 64 <= M) && (n0 + BN <= N);
-    if (PREFETCH_C) {
-#pragma unroll
-      for (int gq = 0; gq < GPT; ++gq) cr[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pre_c) {
-#pragma unroll
-        for (int gq = 0; gq < GPT; ++gq) {
-          const int64_t m = m0 + 64 * pass + ((gq * NTHR + (int)threadIdx.x) >> 5);
-          cr[gq] = Vec4<float>::load(reinterpret_cast<const float*>(ep.C) + m * ep.ldc + n0 + 4 * (threadIdx.x & 31));
-        }
-      }
-    }
-    if (PREFETCH) {
-#pragma unroll
-      for (int gq = 0; gq < GPT; ++gq) { zr[gq] = raw_t{}; rr[gq] = raw_t{}; }
-      if (pre) {
-        const int c4 = threadIdx.x & 31;
-        if (bias) br = Vec4<T>::load_raw(bias + n0 + 4 * c4);
-#pragma unroll
-        for (int gq = 0; gq < GPT; ++gq) {
-          const int64_t m = m0 + 64 * pass + ((gq * NTHR + (int)threadIdx.x) >> 5);
-          if (ep.aux_mode == IMT_AUX_DGELU) zr[gq] = Vec4<T>::load_raw(aux + m * ep.ldaux + n0 + 4 * c4);
-          if (resid) rr[gq] = Vec4<T>::load_raw(resid + m * ep.ldr + n0 + 4 * c4);
-        }
-      }
-    }
-    __syncthreads();  // previous users of smem (K loop / previous pass) are done
-    if (HAS_ACC && active && wm == 64 * pass) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(smem + epi_off(16 * i + lr, (wn + 16 * j + 4 * lg) >> 2)) = acc[i][j] * alpha;
-    }
-    __syncthreads();
-    if (!active) continue;
+    raw_t pr[GPT];   // GELU' input / residual / old C (same type as the operands)
+    f32x4 pc[KIND == EM_F32_ACC ? GPT : 1];
+    const int64_t mrow = m0 + 64 * pass + ((int)threadIdx.x >> 5);  // + gq * (NTHR / 32)
 #pragma unroll
     for (int gq = 0; gq < GPT; ++gq) {
-      const int idx = gq * NTHR + threadIdx.x;
+      const int64_t m = mrow + gq * (NTHR / 32);
+      if (KIND == EM_DGELU) pr[gq] = Vec4<T>::load_raw(aux + m * ep.ldaux + n);
+      if (KIND == EM_RESID || KIND == EM_DROP_RESID) pr[gq] = Vec4<T>::load_raw(resid + m * ep.ldr + n);
+      if (KIND == EM_ACC) pr[gq] = Vec4<T>::load_raw(reinterpret_cast<const T*>(ep.C) + m * ep.ldc + n);
+      if (KIND == EM_F32_ACC) pc[gq] = Vec4<float>::load(reinterpret_cast<const float*>(ep.C) + m * ep.ldc + n);
+    }
+    epi_restage<HAS_ACC, WROWS>(acc, smem, pass, wm, wn, alpha);
+#pragma unroll
+    for (int gq = 0; gq < GPT; ++gq) {
+      const int row = ((int)threadIdx.x >> 5) + gq * (NTHR / 32);
+      const int64_t m = mrow + gq * (NTHR / 32);
+      f32x4 v = *reinterpret_cast<const f32x4*>(smem + epi_off(row, c4)) + bv;
+      if (KIND == EM_GELU) {
+        Vec4<T>::store(aux + m * ep.ldaux + n, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (KIND == EM_DGELU) {
+        const f32x4 z = Vec4<T>::cvt(pr[gq]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
+      }
+      if (KIND == EM_DROP_RESID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? v[e] * ep.inv_keep : 0.f;
+      }
+      if (KIND == EM_RESID || KIND == EM_DROP_RESID || KIND == EM_ACC) v += Vec4<T>::cvt(pr[gq]);
+      if (KIND == EM_F32_ACC) v += pc[gq];
+      if (C32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+      else     Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+    }
+  }
+}
+
+// any tile, any option: one rolled body
+template <typename T, int NTHR, bool HAS_ACC, int WROWS>
+IMT_DEVICE void epilogue_general(const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
+                                 float alpha) {
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  const T* resid = reinterpret_cast<const T*>(ep.resid);
+  T* aux = reinterpret_cast<T*>(ep.aux);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0) epi_restage<HAS_ACC, WROWS>(acc, smem, 0, wm, wn, alpha);
+    else           epi_restage<HAS_ACC, WROWS>(acc, smem, 1, wm, wn, alpha);
+#pragma unroll 1
+    for (int idx = threadIdx.x; idx < 2048; idx += NTHR) {
       const int row = idx >> 5, c4 = idx & 31;
       const int m = m0 + 64 * pass + row, n = n0 + 4 * c4;
       if (m >= M || n >= N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(smem + epi_off(row, c4));
-      if (ep.atomic) {
-        float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < N) atomicAdd(c + e, v[e]);
-        continue;
-      }
-      if (n + 3 < N) {
-        if (bias) v += pre ? Vec4<T>::cvt(br) : Vec4<T>::load(bias + n);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(smem + epi_off(row, c4));
+      if (!ep.atomic && n + 3 < N) {  // whole 4-column group inside the matrix: vector accesses
+        f32x4 v = v4;
+        if (bias) v += Vec4<T>::load(bias + n);
         if (ep.aux_mode == IMT_AUX_GELU_FWD) {
           Vec4<T>::store(aux + (int64_t)m * ep.ldaux + n, v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         } else if (ep.aux_mode == IMT_AUX_DGELU) {
-          const f32x4 z = pre ? Vec4<T>::cvt(zr[gq]) : Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
+          const f32x4 z = Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
         }
@@ -275,43 +318,61 @@ IMT_DEVICE void epilogue(const f32x4 (&acc)[4][4], char* smem, int m0, int n0, i
           for (int e = 0; e < 4; ++e)
             v[e] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? v[e] * ep.inv_keep : 0.f;
         }
-        if (resid) v += pre ? Vec4<T>::cvt(rr[gq]) : Vec4<T>::load(resid + (int64_t)m * ep.ldr + n);
+        if (resid) v += Vec4<T>::load(resid + (int64_t)m * ep.ldr + n);
         if (ep.c_f32) {
           float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
-          if (ep.accumulate) v += pre_c ? cr[PREFETCH_C ? gq : 0] : Vec4<float>::load(c);
+          if (ep.accumulate) v += Vec4<float>::load(c);
           Vec4<float>::store(c, v);
         } else {
           T* c = reinterpret_cast<T*>(ep.C) + (int64_t)m * ep.ldc + n;
           if (ep.accumulate) v += Vec4<T>::load(c);
           Vec4<T>::store(c, v);
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e >= N) break;
-          float x = v[e];
-          if (bias) x += to_f32<T>(bias[n + e]);
-          if (ep.aux_mode == IMT_AUX_GELU_FWD) {
-            aux[(int64_t)m * ep.ldaux + n + e] = from_f32<T>(x);
-            x = gelu_erf(x);
-          } else if (ep.aux_mode == IMT_AUX_DGELU) {
-            x *= gelu_erf_grad(to_f32<T>(aux[(int64_t)m * ep.ldaux + n + e]));
-          }
-          if (ep.drop_thresh)
-            x = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? x * ep.inv_keep : 0.f;
-          if (resid) x += to_f32<T>(resid[(int64_t)m * ep.ldr + n + e]);
-          if (ep.c_f32) {
-            float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n + e;
-            if (ep.accumulate) x += *c;
-            *c = x;
-          } else {
-            T* c = reinterpret_cast<T*>(ep.C) + (int64_t)m * ep.ldc + n + e;
-            if (ep.accumulate) x += to_f32<T>(*c);
-            *c = from_f32<T>(x);
-          }
+        continue;
+      }
+#pragma unroll 1
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) break;
+        float x = e == 0 ? v4[0] : e == 1 ? v4[1] : e == 2 ? v4[2] : v4[3];
+        if (ep.atomic) { atomicAdd(reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n + e, x); continue; }
+        if (bias) x += to_f32<T>(bias[n + e]);
+        if (ep.aux_mode == IMT_AUX_GELU_FWD) {
+          aux[(int64_t)m * ep.ldaux + n + e] = from_f32<T>(x);
+          x = gelu_erf(x);
+        } else if (ep.aux_mode == IMT_AUX_DGELU) {
+          x *= gelu_erf_grad(to_f32<T>(aux[(int64_t)m * ep.ldaux + n + e]));
+        }
+        if (ep.drop_thresh)
+          x = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? x * ep.inv_keep : 0.f;
+        if (resid) x += to_f32<T>(resid[(int64_t)m * ep.ldr + n + e]);
+        if (ep.c_f32) {
+          float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n + e;
+          if (ep.accumulate) x += *c;
+          *c = x;
+        } else {
+          T* c = reinterpret_cast<T*>(ep.C) + (int64_t)m * ep.ldc + n + e;
+          if (ep.accumulate) x += to_f32<T>(*c);
+          *c = from_f32<T>(x);
         }
       }
     }
+  }
+}
+
+template <typename T, int NTHR = NTHREADS, bool HAS_ACC = true, int WROWS = 64>
+IMT_DEVICE void epilogue(const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
+                         float alpha) {
+  const int kind = (m0 + BM <= M && n0 + BN <= N) ? epi_kind(ep) : EM_GENERIC;  // uniform over the workgroup
+  switch (kind) {
+    case EM_PLAIN:      epilogue_fast<T, EM_PLAIN, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_RESID:      epilogue_fast<T, EM_RESID, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_DROP_RESID: epilogue_fast<T, EM_DROP_RESID, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_GELU:       epilogue_fast<T, EM_GELU, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_DGELU:      epilogue_fast<T, EM_DGELU, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_F32:        epilogue_fast<T, EM_F32, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_F32_ACC:    epilogue_fast<T, EM_F32_ACC, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    case EM_ACC:        epilogue_fast<T, EM_ACC, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
+    default:            epilogue_general<T, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
   }
 }
 
@@ -593,6 +654,196 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 256 x 256 tile kernel
+// Every LDS-DMA loop above tops out near 40 GB/s of operand stream per CU, and a 128 x 128 tile needs 32 KiB of it per
+// 4.2 MFLOP -- that, not the MFMA rate, is what holds the short-K products (N >= 2048, K = 512: FFN up, its dX, the
+// vocabulary projection) at 300-600 TFLOP/s.  A 256 x 256 tile halves the bytes per flop: 8 waves as 2 (m) x 4 (n), each
+// 128 x 64 (acc[8][4], 12 fragment reads per 32 MFMAs instead of 8 per 16), operands as four 16-KiB sub-tiles
+// (A rows 0-127 / 128-255, B columns 0-127 / 128-255) in the usual swizzled geometry, two 64-KiB stages: waves 0-3
+// DMA the A sub-tiles, waves 4-7 the B sub-tiles of K tile t+1 while everyone multiplies tile t; one barrier per K tile.
+// The epilogue walks the four 128 x 128 quadrants with all 512 threads (the two owning waves restage, everyone stores).
+constexpr int XL_THREADS = 512;
+constexpr int XL_STAGE = 4 * TILE_BYTES;
+constexpr int XL_LDS = 2 * XL_STAGE;
+
+// One wave's share of TWO neighbouring 16-KiB sub-tiles (operand rows / columns +128): the second sub-tile's source
+// offsets are the first's plus a constant, so a wave keeps 4 offset registers whichever operand it streams.
+template <typename T> struct DmaPair {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[4], kadv, delta, wv;
+  template <bool KCONTIG> IMT_DEVICE void init(const T* base, int64_t ld, int64_t valid_bytes, int row0, int wave) {
+    typedef TileGeom<T, KCONTIG> G;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)valid_bytes, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    wv = wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 64 * (4 * i + wave) + lane;
+      const int tr = q / G::CPR, pc = q % G::CPR;
+      const int c = pc ^ swz<G::RB>(tr);
+      if (KCONTIG) voff[i] = (int)((((int64_t)(row0 + tr)) * ld + c * G::EPC) * (int64_t)sizeof(T));
+      else         voff[i] = (int)((((int64_t)tr) * ld + row0 + c * G::EPC) * (int64_t)sizeof(T));
+    }
+    kadv = KCONTIG ? 128 : (int)(G::BK * ld * (int64_t)sizeof(T));
+    delta = KCONTIG ? (int)(128 * ld * (int64_t)sizeof(T)) : (int)(128 * sizeof(T));
+  }
+  IMT_DEVICE void issue(char* tiles, int t) const {
+    const int wave = __builtin_amdgcn_readfirstlane(wv);
+    const int adv = __builtin_amdgcn_readfirstlane(t * kadv), d = __builtin_amdgcn_readfirstlane(delta);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tiles + h * TILE_BYTES + (4 * i + wave) * 1024),
+                                                 16, voff[i], adv + h * d, 0, 0);
+  }
+};
+
+// Epilogue of a FULL 256 x 256 tile straight from the accumulators: lane (lr, lg) owns 4 consecutive n of row 16i + lr in
+// each of its wave's 8 x 4 MFMA tiles, so bias / aux / C accesses are 8-byte (bf16) vectors, 32 B contiguous per row and
+// instruction, a full 128-B line per row over j = 0..3.  No LDS pass, no barrier, and NO run-time branch: the epilogue
+// kind is a template parameter, because 32 unrolled copies of a body that branches over every option (GELU, GELU',
+// dropout, residual, ...) are ~250 KB of code that a wave walks once, taking an instruction-cache miss at every skipped
+// block -- measured 12-18 us per tile (IMT_GEMM_TRACE), more than the whole K loop.  Kinds outside the table below and
+// ragged edge tiles take the restaged path.
+template <typename T, int AUX, bool C_F32>
+IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, const EpiParams& ep, float alpha) {
+  typedef typename Vec4<T>::type raw_t;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  T* aux = reinterpret_cast<T*>(ep.aux);
+  const int nl = nw + 4 * lg;
+  f32x4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = bias ? Vec4<T>::load(bias + nl + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+  raw_t zr[2][4];
+  auto fetch = [&](int i, int b) {
+    if (AUX == IMT_AUX_DGELU) {
+      const int64_t m = mw + 16 * i + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zr[b][j] = Vec4<T>::load_raw(aux + m * ep.ldaux + nl + 16 * j);
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i + 1 < 8) fetch(i + 1, (i + 1) & 1);  // requested before this group's stores: the wait below never covers a store
+    const int64_t m = mw + 16 * i + lr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nl + 16 * j;
+      f32x4 v = acc[i][j] * alpha + bv[j];
+      if (AUX == IMT_AUX_GELU_FWD) {
+        Vec4<T>::store(aux + m * ep.ldaux + n, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (AUX == IMT_AUX_DGELU) {
+        const f32x4 z = Vec4<T>::cvt(zr[i & 1][j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
+      }
+      if (C_F32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+      else       Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+    }
+  }
+}
+
+template <typename T, int LAYOUT>
+IMT_DEVICE void compute_tile_xl(f32x4 (&acc)[8][4], const char* ta, const char* tb, int wn) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  typedef TileGeom<T, A_KC> GA;
+  typedef TileGeom<T, B_KC> GB;
+  typedef typename Frag<T>::type frag_t;
+  constexpr int KSTEP = Frag<T>::KSTEP;
+#pragma unroll
+  for (int s = 0; s < GA::BK / KSTEP; ++s) {
+    frag_t fa[8], fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (B_KC) fb[j] = lds_frag_kcontig<T, GB::RB>(tb, wn + 16 * j, 4 * s);
+      else      fb[j] = KStrided<T, GB::RB>::load(tb, s * KSTEP, wn + 16 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (A_KC) fa[i] = lds_frag_kcontig<T, GA::RB>(ta, 16 * i, 4 * s);
+      else      fa[i] = KStrided<T, GA::RB>::load(ta, s * KSTEP, 16 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma16(acc[i][j], fb[j], fa[i]);
+    // keep the next K step's 12 fragment reads below this step's MFMAs: hoisted, they push the 128 accumulator
+    // registers + 2 x 48 fragment registers past the 256 a wave gets at two waves per SIMD (spills in the loop)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict__ A, int64_t lda, int64_t a_bytes,
+                                                             const T* __restrict__ B, int64_t ldb, int64_t b_bytes, int M, int N,
+                                                             int K, EpiParams ep) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  constexpr int BK = TileGeom<T, A_KC>::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
+  const int bid = imt_xcd_block(blockIdx.x, nbx * nby);
+  const int m0 = (bid / nbx) * 256, n0 = (bid % nbx) * 256;
+  const int nt = K / BK;  // host guarantees whole K tiles
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wmi = wave >> 2, wni = wave & 3, wn = (wni & 1) * 64;
+  const bool loads_a = wave < 4;
+
+  auto stamp = [&](int k) { if (ep.trace && threadIdx.x == 0) ep.trace[blockIdx.x * 4 + k] = wall_clock64(); };
+  stamp(0);
+  DmaPair<T> dma;
+  if (loads_a) dma.template init<A_KC>(A, lda, a_bytes, m0, wave);
+  else         dma.template init<B_KC>(B, ldb, b_bytes, n0, wave - 4);
+  auto issue = [&](int slot, int t) { dma.issue(smem + slot * XL_STAGE + (loads_a ? 0 : 2 * TILE_BYTES), t); };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // K-order rotation: the workgroups of a launch run in lock-step, and with power-of-two row pitches the same K tile of
+  // every row lives on the same few L2 channels -- start each workgroup at a different K tile (summation order only)
+  const int rot = ep.dbg & 4 ? 0 : (int)((blockIdx.x * 5u + blockIdx.x / 8u) % (unsigned)(nt > 0 ? nt : 1));
+  auto ktile = [&](int t) { const int k = t + rot; return k >= nt ? k - nt : k; };
+  if (nt > 0) issue(0, ktile(0));
+  for (int t = 0; t < nt; ++t) {
+    // my eight pieces of tile t have landed; the barrier publishes everyone's and proves that the other stage (read
+    // while multiplying tile t-1) is free for the DMA of tile t+1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (t + 1 < nt) issue((t + 1) & 1, ktile(t + 1));
+    if (t == 0) stamp(1);
+    const char* st = smem + (t & 1) * XL_STAGE;
+    compute_tile_xl<T, LAYOUT>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
+  }
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+  stamp(2);
+  if (m0 + 256 <= M && n0 + 256 <= N && !ep.atomic && !ep.accumulate && !ep.resid && !ep.drop_thresh && !(ep.dbg & 8)) {
+    const int mw = m0 + 128 * wmi, nw = n0 + 64 * wni;
+    bool done = true;
+    if (ep.aux_mode == IMT_AUX_NONE && !ep.c_f32)          epilogue_xl_direct<T, IMT_AUX_NONE, false>(acc, mw, nw, ep, alpha);
+    else if (ep.aux_mode == IMT_AUX_NONE)                  epilogue_xl_direct<T, IMT_AUX_NONE, true>(acc, mw, nw, ep, alpha);
+    else if (ep.aux_mode == IMT_AUX_GELU_FWD && !ep.c_f32) epilogue_xl_direct<T, IMT_AUX_GELU_FWD, false>(acc, mw, nw, ep, alpha);
+    else if (ep.aux_mode == IMT_AUX_DGELU && !ep.c_f32)    epilogue_xl_direct<T, IMT_AUX_DGELU, false>(acc, mw, nw, ep, alpha);
+    else done = false;
+    if (done) { stamp(3); return; }
+  }
+  // ragged edge tiles: the bounds-checked restaged epilogue, one 128 x 128 quadrant at a time
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int qm = q >> 1, qn = q & 1;
+    const int mq = m0 + 128 * qm, nq = n0 + 128 * qn;
+    if (mq >= M || nq >= N) continue;  // uniform over the workgroup
+    if (wmi == qm && (wni >> 1) == qn) epilogue<T, XL_THREADS, true, 128>(acc, smem, mq, nq, 0, wn, M, N, ep, alpha);
+    else                               epilogue<T, XL_THREADS, false, 128>(acc, smem, mq, nq, 0, wn, M, N, ep, alpha);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ grouped weight gradients
 // All weight-gradient GEMMs of one transformer layer (dW = dy^T x, K = tokens) in ONE launch: each has only 16-64
 // output tiles, so separately they either idle most CUs or need split-K atomics; together they are ~one tile per
@@ -678,7 +929,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
   ep.C = P.C; ep.ldc = P.ldc; ep.c_f32 = 1; ep.accumulate = 1;
   ep.bias = nullptr; ep.resid = nullptr; ep.ldr = 0; ep.aux = nullptr; ep.ldaux = 0; ep.aux_mode = IMT_AUX_NONE;
   ep.atomic = 0; ep.alpha = g.alpha; ep.alpha_dev = nullptr; ep.inv_keep = 1.f; ep.drop_thresh = 0; ep.seed = 0;
-  ep.a_colsum = P.a_colsum; ep.dbg = 0;
+  ep.a_colsum = P.a_colsum; ep.dbg = 0; ep.trace = nullptr;
   // one tile per workgroup: the epilogue is fully exposed, so all 8 waves share it (the producers have nothing left to do)
   if (consumer) epilogue<T, 512, true>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
   else epilogue<T, 512, false>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
@@ -704,21 +955,58 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
   }
   // profiler kind == one kernel symbol: gemm_<variant>_<dtype>_<layout> (variant: dbuf = gemm_kernel, dma = gemm_pipe_kernel,
   // sbuf = gemm_sb_kernel, ws = gemm_ws_kernel) so that rocprofv3's per-symbol averages can be compared one to one
-  static const char* const kinds[6][2][3] = {
+  static const char* const kinds[7][2][3] = {
       {{"", "", ""}, {"", "", ""}},
       {{"gemm_dbuf_f32_nt", "gemm_dbuf_f32_nn", "gemm_dbuf_f32_tn"}, {"gemm_dbuf_bf16_nt", "gemm_dbuf_bf16_nn", "gemm_dbuf_bf16_tn"}},
       {{"gemm_dma_f32_nt", "gemm_dma_f32_nn", "gemm_dma_f32_tn"}, {"gemm_dma_bf16_nt", "gemm_dma_bf16_nn", "gemm_dma_bf16_tn"}},
       {{"gemm_sbuf_f32_nt", "gemm_sbuf_f32_nn", "gemm_sbuf_f32_tn"}, {"gemm_sbuf_bf16_nt", "gemm_sbuf_bf16_nn", "gemm_sbuf_bf16_tn"}},
       {{"gemm_dma_f32_nt", "gemm_dma_f32_nn", "gemm_dma_f32_tn"}, {"gemm_dma_bf16_nt", "gemm_dma_bf16_nn", "gemm_dma_bf16_tn"}},
-      {{"gemm_ws_f32_nt", "gemm_ws_f32_nn", "gemm_ws_f32_tn"}, {"gemm_ws_bf16_nt", "gemm_ws_bf16_nn", "gemm_ws_bf16_tn"}}};
+      {{"gemm_ws_f32_nt", "gemm_ws_f32_nn", "gemm_ws_f32_tn"}, {"gemm_ws_bf16_nt", "gemm_ws_bf16_nn", "gemm_ws_bf16_tn"}},
+      {{"gemm_xl_f32_nt", "gemm_xl_f32_nn", "gemm_xl_f32_tn"}, {"gemm_xl_bf16_nt", "gemm_xl_bf16_nn", "gemm_xl_bf16_tn"}}};
   const double es = sizeof(T), esc = ep.c_f32 ? 4.0 : es;
-  const char* kind = kinds[variant >= 1 && variant <= 5 ? variant : 1][sizeof(T) == 2][LAYOUT];
+  const char* kind = kinds[variant >= 1 && variant <= 6 ? variant : 1][sizeof(T) == 2][LAYOUT];
   if (imt_prof_enabled() && getenv("IMT_PROF_SHAPES")) kind = imt_prof_intern(kind, a->M, a->N, a->K);
   ImtProfScope prof(kind, 2.0 * a->M * a->N * a->K,
                     ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * esc, st);
   const T* A = reinterpret_cast<const T*>(a->A);
   const T* B = reinterpret_cast<const T*>(a->B);
-  if (variant == 5) {
+  if (variant == 6) {
+    static bool xl_attr = false;
+    auto kxl = gemm_xl_kernel<T, LAYOUT>;
+    if (!xl_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kxl), hipFuncAttributeMaxDynamicSharedMemorySize, XL_LDS); xl_attr = true; }
+    const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
+    const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
+    const int nwg = imt_cdiv(a->M, 256) * imt_cdiv(a->N, 256);
+    static const bool trace = getenv("IMT_GEMM_TRACE") != nullptr;
+    if (trace) {
+      // tuning aid (synchronises!): phase time stamps (100 MHz wall clock) of every workgroup of this launch
+      static unsigned long long* dbuf = nullptr;
+      if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 4 * sizeof(unsigned long long));
+      EpiParams ept = ep;
+      ept.trace = nwg <= 4096 ? dbuf : nullptr;
+      (void)hipMemsetAsync(dbuf, 0, 4096 * 4 * sizeof(unsigned long long), st);
+      hipLaunchKernelGGL(kxl, dim3(nwg), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ept);
+      (void)hipStreamSynchronize(st);
+      static unsigned long long host[4096 * 4];
+      (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull, t3 = 0;
+      double fill = 0, loop = 0, epi = 0;
+      int cnt = 0;
+      for (int b = 0; b < nwg && b < 4096; ++b) {
+        const unsigned long long* h = host + 4 * b;
+        if (!h[3]) continue;
+        if (h[0] < t0) t0 = h[0];
+        if (h[3] > t3) t3 = h[3];
+        fill += (h[1] - h[0]) * 0.01; loop += (h[2] - h[1]) * 0.01; epi += (h[3] - h[2]) * 0.01; ++cnt;
+      }
+      unsigned long long smax = 0;
+      for (int b = 0; b < nwg && b < 4096; ++b) if (host[4 * b + 3] && host[4 * b] - t0 > smax) smax = host[4 * b] - t0;
+      if (cnt) fprintf(stderr, "[xl trace] %dx%dx%d: %d full workgroups, first start -> last end %.2f us; latest start +%.2f us; mean fill %.2f loop %.2f epilogue %.2f us\n",
+                       a->M, a->N, a->K, cnt, (t3 - t0) * 0.01, smax * 0.01, fill / cnt, loop / cnt, epi / cnt);
+    } else {
+      hipLaunchKernelGGL(kxl, dim3(nwg), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ep);
+    }
+  } else if (variant == 5) {
     static bool ws_attr = false;
     auto kws = gemm_ws_kernel<T, LAYOUT>;
     if (!ws_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kws), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS); ws_attr = true; }
@@ -833,6 +1121,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     static const bool prefer_small = getenv("IMT_GEMM_SHARE_CUS") != nullptr;
     if (prefer_small && variant == 5 && a->layout != IMT_TN && tiles > 192 && tiles <= 256 && a->K < 1024) variant = 3;
   }
+  if (variant == 6 && (!pipe_ok || splits > 1 || a->a_colsum)) variant = 3;
   if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;
   if (variant == 5 && (!pipe_ok || splits > 1)) variant = 3;
   EpiParams ep;
@@ -846,6 +1135,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   ep.seed = a->dropout_seed;
   ep.a_colsum = a->a_colsum;
   ep.dbg = dbg;
+  ep.trace = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == IMT_F32) return dispatch<float>(a, ep, splits, kps, variant, st);
   return dispatch<bf16_t>(a, ep, splits, kps, variant, st);
