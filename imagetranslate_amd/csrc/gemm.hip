@@ -806,17 +806,14 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // K-order rotation: the workgroups of a launch run in lock-step, and with power-of-two row pitches the same K tile of
-  // every row lives on the same few L2 channels -- start each workgroup at a different K tile (summation order only)
-  const int rot = ep.dbg & 4 ? 0 : (int)((blockIdx.x * 5u + blockIdx.x / 8u) % (unsigned)(nt > 0 ? nt : 1));
-  auto ktile = [&](int t) { const int k = t + rot; return k >= nt ? k - nt : k; };
-  if (nt > 0) issue(0, ktile(0));
+  // (no K-order rotation: measured no gain here, and the same K order keeps results bit-identical to the other kernels)
+  if (nt > 0) issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     // my eight pieces of tile t have landed; the barrier publishes everyone's and proves that the other stage (read
     // while multiplying tile t-1) is free for the DMA of tile t+1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    if (t + 1 < nt) issue((t + 1) & 1, ktile(t + 1));
+    if (t + 1 < nt) issue((t + 1) & 1, t + 1);
     if (t == 0) stamp(1);
     const char* st = smem + (t & 1) * XL_STAGE;
     compute_tile_xl<T, LAYOUT>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
@@ -1116,6 +1113,13 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
     if (pipe_ok && splits == 1 && (tiles <= 256 || a->K >= 1024)) variant = 5;
     else variant = (a->layout == IMT_TN) ? 1 : 3;
+    // 256 x 256 tiles (profiles/r01_gemm_xl_study.txt): several rounds of short-K tiles (vocabulary projection 797 vs 681
+    // TFLOP/s, batched cross K/V), or one round whose epilogue reads a second matrix (GELU', residual: 500 vs 430)
+    const int64_t tiles256 = (int64_t)imt_cdiv(a->M, 256) * imt_cdiv(a->N, 256);
+    static const bool no_xl = getenv("IMT_GEMM_NO_XL") != nullptr;
+    if (!no_xl && pipe_ok && splits == 1 && a->layout != IMT_TN && !a->a_colsum && a->K < 1024 &&
+        (tiles256 >= 512 || (tiles256 >= 224 && (a->aux_mode == IMT_AUX_DGELU || a->resid))))
+      variant = 6;
     // data-parallel knob (off by default): when a collective's kernels hold some CUs, a persistent
     // launch of exactly one tile per CU needs a full second round; three small workgroups per CU degrade gracefully
     static const bool prefer_small = getenv("IMT_GEMM_SHARE_CUS") != nullptr;

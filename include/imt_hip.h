@@ -96,7 +96,8 @@ typedef struct imt_gemm_args {
   int32_t force_general;  /* tests / tuning: kernel variant, 0 = auto, 1 = register-staged double buffer (2 blocks/CU),
                              2 / 4 = LDS-DMA 3- / 4-stage ring (1 block/CU; K a whole number of tiles), 3 = single LDS
                              buffer + register prefetch (3 blocks/CU), 5 = persistent wave-specialised (LDS-DMA
-                             producer waves, K a whole number of tiles) */
+                             producer waves, K a whole number of tiles), 6 = 256 x 256 tiles (NT / NN, K a whole
+                             number of tiles) */
   int32_t force_pipeline; /* reserved */
 } imt_gemm_args;
 int imt_gemm(const imt_gemm_args* a, void* stream);

@@ -151,7 +151,7 @@ def test_gemm_pipelined_vs_general_kernel(cuda, dtype, layout):
         da = wa.to(dtype).to(cuda)[:, 8:8 + a_in.shape[1]]
         db = wb.to(dtype).to(cuda)[:, 16:16 + b_in.shape[1]]
         outs = []
-        for force in (2, 1, 3, 5):  # LDS-DMA ring, register double buffer, single buffer, persistent wave-specialised
+        for force in (2, 1, 3, 5, 6):  # LDS-DMA ring, register double buffer, single buffer, persistent wave-specialised, 256-tile
             out = torch.zeros((M, N), device=cuda, dtype=torch.float32)
             O.gemm(da, db, layout, out=out, split_k=sk if layout == O.IMT_TN else 1,
                    accumulate=False, force_general=force)
@@ -161,13 +161,14 @@ def test_gemm_pipelined_vs_general_kernel(cuda, dtype, layout):
         assert torch.equal(outs[1], ref), "general kernel wrong"
         assert torch.equal(outs[2], ref), "single-buffer kernel wrong"
         assert torch.equal(outs[3], ref), "wave-specialised kernel wrong"
+        assert torch.equal(outs[4], ref), "256 x 256-tile kernel wrong"
 
 
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues_agree_across_kernel_variants(cuda, dtype, layout):
     """Every kernel variant (single buffer, register double buffer, persistent wave-specialised with several tiles
-    per workgroup) must produce BIT-IDENTICAL results for every epilogue the train step uses, on ragged M / N."""
+    per workgroup, 256 x 256 tiles with their direct epilogue on full tiles) must produce BIT-IDENTICAL results for every epilogue the train step uses, on ragged M / N."""
     from imagetranslate_amd import hip_ops as O
     g = torch.Generator().manual_seed(21)
     bk = 64 if dtype == torch.bfloat16 else 32
@@ -182,7 +183,7 @@ def test_gemm_epilogues_agree_across_kernel_variants(cuda, dtype, layout):
                  dict(bias=bias, dropout_p=0.1, dropout_seed=77, resid=resid), dict(resid=resid), dict(alpha=0.25, resid=resid)]
         for kw in cases:
             outs, auxs = [], []
-            for force in (3, 1, 5):
+            for force in (3, 1, 5, 6):
                 aux = None
                 if kw.get("aux_mode") == O.IMT_AUX_GELU_FWD:
                     aux = torch.zeros(M, N, device=cuda, dtype=dtype)
@@ -198,10 +199,11 @@ def test_gemm_epilogues_agree_across_kernel_variants(cuda, dtype, layout):
                 assert auxs[0] is None or torch.equal(auxs[0], x)
         # fp32 output with accumulate (the form the runtime uses for C += ...)
         c0 = torch.randn(M, N, generator=g).to(cuda)
-        o3, o5 = c0.clone(), c0.clone()
+        o3, o5, o6 = c0.clone(), c0.clone(), c0.clone()
         O.gemm(A, B, layout, out=o3, accumulate=True, force_general=3)
         O.gemm(A, B, layout, out=o5, accumulate=True, force_general=5)
-        assert torch.equal(o3.cpu(), o5.cpu())
+        O.gemm(A, B, layout, out=o6, accumulate=True, force_general=6)
+        assert torch.equal(o3.cpu(), o5.cpu()) and torch.equal(o3.cpu(), o6.cpu())
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
