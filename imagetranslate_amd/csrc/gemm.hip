@@ -232,8 +232,8 @@ IMT_DEVICE void epi_restage(const f32x4 (*acc)[4], char* smem, int pass, int wm,
 
 // full tile, kind known at compile time: no bounds checks, no branches; the per-element operands of a pass (GELU' input,
 // residual, old C) are requested before the tile is restaged and stay in flight across the two barriers
-template <typename T, int KIND, int NTHR, bool HAS_ACC, int WROWS>
-IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int N, const EpiParams& ep, float alpha) {
+template <typename T, int KIND, int NTHR, bool HAS_ACC, int WROWS, bool RAGGED_M>
+IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep, float alpha) {
   typedef typename Vec4<T>::type raw_t;
   constexpr int GPT = 2048 / NTHR;  // 4-column groups per thread per 64-row pass
   constexpr bool C32 = (KIND == EM_F32 || KIND == EM_F32_ACC);
@@ -249,7 +249,9 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
     const int64_t mrow = m0 + 64 * pass + ((int)threadIdx.x >> 5);  // + gq * (NTHR / 32)
 #pragma unroll
     for (int gq = 0; gq < GPT; ++gq) {
-      const int64_t m = mrow + gq * (NTHR / 32);
+      // ragged M (8128 target rows): loads of the rows past M read row M-1 instead (no control flow around a load: a
+      // branch makes the compiler drain vmcnt at every join), only the stores below are predicated
+      const int64_t m = RAGGED_M ? min((int64_t)(mrow + gq * (NTHR / 32)), (int64_t)M - 1) : mrow + gq * (NTHR / 32);
       if (KIND == EM_DGELU) pr[gq] = Vec4<T>::load_raw(aux + m * ep.ldaux + n);
       if (KIND == EM_RESID || KIND == EM_DROP_RESID) pr[gq] = Vec4<T>::load_raw(resid + m * ep.ldr + n);
       if (KIND == EM_ACC) pr[gq] = Vec4<T>::load_raw(reinterpret_cast<const T*>(ep.C) + m * ep.ldc + n);
@@ -260,9 +262,10 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
     for (int gq = 0; gq < GPT; ++gq) {
       const int row = ((int)threadIdx.x >> 5) + gq * (NTHR / 32);
       const int64_t m = mrow + gq * (NTHR / 32);
+      const bool live = !RAGGED_M || m < M;
       f32x4 v = *reinterpret_cast<const f32x4*>(smem + epi_off(row, c4)) + bv;
       if (KIND == EM_GELU) {
-        Vec4<T>::store(aux + m * ep.ldaux + n, v);
+        if (live) Vec4<T>::store(aux + m * ep.ldaux + n, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       }
@@ -278,8 +281,10 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
       }
       if (KIND == EM_RESID || KIND == EM_DROP_RESID || KIND == EM_ACC) v += Vec4<T>::cvt(pr[gq]);
       if (KIND == EM_F32_ACC) v += pc[gq];
-      if (C32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
-      else     Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+      if (live) {
+        if (C32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+        else     Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+      }
     }
   }
 }
@@ -359,21 +364,28 @@ IMT_DEVICE void epilogue_general(const f32x4 (*acc)[4], char* smem, int m0, int 
   }
 }
 
+template <typename T, int NTHR, bool HAS_ACC, int WROWS, bool RAGGED_M>
+IMT_DEVICE void epilogue_fast_kinds(int kind, const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int M, int N,
+                                    const EpiParams& ep, float alpha) {
+  switch (kind) {
+    case EM_PLAIN:      epilogue_fast<T, EM_PLAIN, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    case EM_RESID:      epilogue_fast<T, EM_RESID, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    case EM_DROP_RESID: epilogue_fast<T, EM_DROP_RESID, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    case EM_GELU:       epilogue_fast<T, EM_GELU, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    case EM_DGELU:      epilogue_fast<T, EM_DGELU, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    case EM_F32:        epilogue_fast<T, EM_F32, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    case EM_F32_ACC:    epilogue_fast<T, EM_F32_ACC, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+    default:            epilogue_fast<T, EM_ACC, NTHR, HAS_ACC, WROWS, RAGGED_M>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
+  }
+}
+
 template <typename T, int NTHR = NTHREADS, bool HAS_ACC = true, int WROWS = 64>
 IMT_DEVICE void epilogue(const f32x4 (*acc)[4], char* smem, int m0, int n0, int wm, int wn, int M, int N, const EpiParams& ep,
                          float alpha) {
-  const int kind = (m0 + BM <= M && n0 + BN <= N) ? epi_kind(ep) : EM_GENERIC;  // uniform over the workgroup
-  switch (kind) {
-    case EM_PLAIN:      epilogue_fast<T, EM_PLAIN, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_RESID:      epilogue_fast<T, EM_RESID, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_DROP_RESID: epilogue_fast<T, EM_DROP_RESID, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_GELU:       epilogue_fast<T, EM_GELU, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_DGELU:      epilogue_fast<T, EM_DGELU, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_F32:        epilogue_fast<T, EM_F32, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_F32_ACC:    epilogue_fast<T, EM_F32_ACC, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    case EM_ACC:        epilogue_fast<T, EM_ACC, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, N, ep, alpha); break;
-    default:            epilogue_general<T, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha); break;
-  }
+  const int kind = (n0 + BN <= N) ? epi_kind(ep) : EM_GENERIC;  // uniform over the workgroup
+  if (kind == EM_GENERIC || ((ep.dbg & 16) && m0 + BM > M)) epilogue_general<T, NTHR, HAS_ACC, WROWS>(acc, smem, m0, n0, wm, wn, M, N, ep, alpha);
+  else if (m0 + BM <= M)  epilogue_fast_kinds<T, NTHR, HAS_ACC, WROWS, false>(kind, acc, smem, m0, n0, wm, wn, M, N, ep, alpha);
+  else                    epilogue_fast_kinds<T, NTHR, HAS_ACC, WROWS, true>(kind, acc, smem, m0, n0, wm, wn, M, N, ep, alpha);
 }
 
 // XCD-aware block order (T1): consecutive ids on one XCD walk neighbouring tiles (bijective for any grid size).
@@ -706,8 +718,8 @@ template <typename T> struct DmaPair {
 // dropout, residual, ...) are ~250 KB of code that a wave walks once, taking an instruction-cache miss at every skipped
 // block -- measured 12-18 us per tile (IMT_GEMM_TRACE), more than the whole K loop.  Kinds outside the table below and
 // ragged edge tiles take the restaged path.
-template <typename T, int AUX, bool C_F32>
-IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, const EpiParams& ep, float alpha) {
+template <typename T, int AUX, bool C_F32, bool RAGGED_M>
+IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, int M, const EpiParams& ep, float alpha) {
   typedef typename Vec4<T>::type raw_t;
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const T* bias = reinterpret_cast<const T*>(ep.bias);
@@ -719,7 +731,8 @@ IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, con
   raw_t zr[2][4];
   auto fetch = [&](int i, int b) {
     if (AUX == IMT_AUX_DGELU) {
-      const int64_t m = mw + 16 * i + lr;
+      // ragged M: clamped loads, predicated stores
+      const int64_t m = RAGGED_M ? min((int64_t)(mw + 16 * i + lr), (int64_t)M - 1) : (int64_t)(mw + 16 * i + lr);
 #pragma unroll
       for (int j = 0; j < 4; ++j) zr[b][j] = Vec4<T>::load_raw(aux + m * ep.ldaux + nl + 16 * j);
     }
@@ -729,12 +742,13 @@ IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, con
   for (int i = 0; i < 8; ++i) {
     if (i + 1 < 8) fetch(i + 1, (i + 1) & 1);  // requested before this group's stores: the wait below never covers a store
     const int64_t m = mw + 16 * i + lr;
+    const bool live = !RAGGED_M || m < M;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nl + 16 * j;
       f32x4 v = acc[i][j] * alpha + bv[j];
       if (AUX == IMT_AUX_GELU_FWD) {
-        Vec4<T>::store(aux + m * ep.ldaux + n, v);
+        if (live) Vec4<T>::store(aux + m * ep.ldaux + n, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       } else if (AUX == IMT_AUX_DGELU) {
@@ -742,8 +756,10 @@ IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, con
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
       }
-      if (C_F32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
-      else       Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+      if (live) {
+        if (C_F32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+        else       Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+      }
     }
   }
 }
@@ -820,13 +836,23 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
   stamp(2);
-  if (m0 + 256 <= M && n0 + 256 <= N && !ep.atomic && !ep.accumulate && !ep.resid && !ep.drop_thresh && !(ep.dbg & 8)) {
+  if (n0 + 256 <= N && !ep.atomic && !ep.accumulate && !ep.resid && !ep.drop_thresh && !(ep.dbg & 8)) {
     const int mw = m0 + 128 * wmi, nw = n0 + 64 * wni;
     bool done = true;
-    if (ep.aux_mode == IMT_AUX_NONE && !ep.c_f32)          epilogue_xl_direct<T, IMT_AUX_NONE, false>(acc, mw, nw, ep, alpha);
-    else if (ep.aux_mode == IMT_AUX_NONE)                  epilogue_xl_direct<T, IMT_AUX_NONE, true>(acc, mw, nw, ep, alpha);
-    else if (ep.aux_mode == IMT_AUX_GELU_FWD && !ep.c_f32) epilogue_xl_direct<T, IMT_AUX_GELU_FWD, false>(acc, mw, nw, ep, alpha);
-    else if (ep.aux_mode == IMT_AUX_DGELU && !ep.c_f32)    epilogue_xl_direct<T, IMT_AUX_DGELU, false>(acc, mw, nw, ep, alpha);
+    const bool rag = m0 + 256 > M;
+    if (ep.aux_mode == IMT_AUX_NONE && !ep.c_f32) {
+      if (rag) epilogue_xl_direct<T, IMT_AUX_NONE, false, true>(acc, mw, nw, M, ep, alpha);
+      else     epilogue_xl_direct<T, IMT_AUX_NONE, false, false>(acc, mw, nw, M, ep, alpha);
+    } else if (ep.aux_mode == IMT_AUX_NONE) {
+      if (rag) epilogue_xl_direct<T, IMT_AUX_NONE, true, true>(acc, mw, nw, M, ep, alpha);
+      else     epilogue_xl_direct<T, IMT_AUX_NONE, true, false>(acc, mw, nw, M, ep, alpha);
+    } else if (ep.aux_mode == IMT_AUX_GELU_FWD && !ep.c_f32) {
+      if (rag) epilogue_xl_direct<T, IMT_AUX_GELU_FWD, false, true>(acc, mw, nw, M, ep, alpha);
+      else     epilogue_xl_direct<T, IMT_AUX_GELU_FWD, false, false>(acc, mw, nw, M, ep, alpha);
+    } else if (ep.aux_mode == IMT_AUX_DGELU && !ep.c_f32) {
+      if (rag) epilogue_xl_direct<T, IMT_AUX_DGELU, false, true>(acc, mw, nw, M, ep, alpha);
+      else     epilogue_xl_direct<T, IMT_AUX_DGELU, false, false>(acc, mw, nw, M, ep, alpha);
+    }
     else done = false;
     if (done) { stamp(3); return; }
   }
@@ -1103,7 +1129,8 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   // kernel variant: 1 = register-staged double buffer (2 blocks/CU), 2 = LDS-DMA 3-stage ring (1 block/CU),
   // 3 = single buffer + register prefetch (4 blocks/CU).  a->force_general carries a variant code for tests/tuning.
   int variant = a->force_general % 100;
-  const int dbg = a->force_general / 100;
+  static const int env_dbg = getenv("IMT_GEMM_DBG") ? atoi(getenv("IMT_GEMM_DBG")) : 0;  // tuning only
+  const int dbg = a->force_general / 100 | env_dbg;
   // measured on MI355X (profiles/r01_v3_gemm_shapes.txt): about one wave of blocks -> the LDS-DMA ring (its long
   // steady state wins when K >= 1024, a tie otherwise); larger grids -> three single-buffer blocks per CU.
   // measured on MI355X (profiles/r01_v5_gemm_shapes.txt): the persistent wave-specialised kernel wins whenever a CU
