@@ -34,6 +34,7 @@ struct AttnP {
   void* dQ; int64_t lddq;
   void* dK; int64_t lddk;
   void* dV; int64_t lddv;
+  unsigned long long* trace;  // tuning only (IMT_TRACE)
   float* delta;
 };
 
@@ -41,11 +42,21 @@ struct AttnP {
 template <typename T, int DH>
 IMT_DEVICE void stage_tile(char* tile, const T* base, int64_t ld, int row0, int nrows) {
   constexpr int RB = DH * sizeof(T), CPR = RB / 16, EPC = 16 / sizeof(T);
-  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
-    const int tr = q / CPR, c = q % CPR;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row0 + tr < nrows) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + tr) * ld + c * EPC);
-    *reinterpret_cast<u32x4*>(tile + tile_off<RB>(tr, c)) = v;
+  // loads first and unconditional (rows past the end read row nrows-1 and are zeroed by a select): a load under a
+  // branch merges with the zero through a phi, and the copy at the join drains vmcnt -- one round trip per load
+  constexpr int NIT = 64 * CPR / 256;
+  static_assert(64 * CPR % 256 == 0, "tile chunks must divide evenly over 256 threads");
+  u32x4 v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = threadIdx.x + it * 256, tr = q / CPR, c = q % CPR;
+    v[it] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(row0 + tr, nrows - 1) * ld + c * EPC);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = threadIdx.x + it * 256, tr = q / CPR, c = q % CPR;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(tile + tile_off<RB>(tr, c)) = (row0 + tr < nrows) ? v[it] : z;
   }
 }
 
@@ -58,9 +69,9 @@ IMT_DEVICE void load_row_frags(typename Frag<T>::type (&f)[DH * sizeof(T) / 64],
   typedef typename Frag<T>::type frag_t;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row0 + r < nrows) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + r) * ld + (4 * s + g) * EPC);
-    f[s] = __builtin_bit_cast(frag_t, v);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)min(row0 + r, nrows - 1) * ld + (4 * s + g) * EPC);
+    f[s] = __builtin_bit_cast(frag_t, (row0 + r < nrows) ? v : z);  // unconditional load + select (see stage_tile)
   }
 }
 
@@ -217,27 +228,36 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
   const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
   const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
   const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
-  {
-    constexpr int CPR = RB / 16;
-    for (int q = threadIdx.x; q < 128 * CPR; q += 512) {
-      const int tr = q / CPR, c = q % CPR;
-      u32x4 vk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-      if (tr < p.Tk) {
-        vk = *reinterpret_cast<const u32x4*>(Kb + (int64_t)tr * p.ldk + c * 8);
-        vv = *reinterpret_cast<const u32x4*>(Vb + (int64_t)tr * p.ldv + c * 8);
-      }
-      *reinterpret_cast<u32x4*>(Ks + tile_off<RB>(tr, c)) = vk;
-      *reinterpret_cast<u32x4*>(Vs + tile_off<RB>(tr, c)) = vv;
-    }
-    if (threadIdx.x < 128) {
-      const int j = threadIdx.x;
-      kmask_s[j] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
-    }
+  // every global load of the kernel is requested here, unconditionally (clamped rows, a valid stand-in address for an
+  // absent mask) and before the first use: ONE memory round trip in front of the barrier instead of one per load
+  IMT_STAMP(p.trace, 0);
+  constexpr int CPR = RB / 16, NIT = 128 * CPR / 512;
+  u32x4 vk[NIT], vv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = threadIdx.x + it * 512, tr = min(q / CPR, p.Tk - 1), c = q % CPR;
+    vk[it] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)tr * p.ldk + c * 8);
+    vv[it] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)tr * p.ldv + c * 8);
   }
   frag_t qf[NS];
   load_row_frags<T, DH>(qf, Qb, p.ldq, q0, p.Tq);
-  const bool query_ok = (p.query_mask && i < p.Tq) ? (p.query_mask[(int64_t)b * p.Tq + i] != 0) : true;
+  const uint8_t* kmp = p.key_mask ? p.key_mask + (int64_t)b * p.Tk + min((int)threadIdx.x & 127, p.Tk - 1) : reinterpret_cast<const uint8_t*>(Kb);
+  const uint8_t* qmp = p.query_mask ? p.query_mask + (int64_t)b * p.Tq + min(i, p.Tq - 1) : reinterpret_cast<const uint8_t*>(Qb);
+  const uint8_t kmv = *kmp, qmv = *qmp;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = threadIdx.x + it * 512, tr = q / CPR, c = q % CPR;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(Ks + tile_off<RB>(tr, c)) = (tr < p.Tk) ? vk[it] : z;
+    *reinterpret_cast<u32x4*>(Vs + tile_off<RB>(tr, c)) = (tr < p.Tk) ? vv[it] : z;
+  }
+  if (threadIdx.x < 128) {
+    const int j = threadIdx.x;
+    kmask_s[j] = (j < p.Tk) ? (p.key_mask ? kmv : (uint8_t)1) : (uint8_t)0;
+  }
+  const bool query_ok = (p.query_mask && i < p.Tq) ? (qmv != 0) : true;
   __syncthreads();
+  IMT_STAMP(p.trace, 1);
   if (q0 >= p.Tq) return;  // whole wave past the last query (no barrier follows)
 
   // S^T: 8 tiles of 16 keys x this wave's 16 queries
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
   }
   tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+  IMT_STAMP(p.trace, 2);
   float psum = 0.f;
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt)
@@ -275,6 +296,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
     }
   psum += __shfl_xor(psum, 16, 64);
   psum += __shfl_xor(psum, 32, 64);
+  IMT_STAMP(p.trace, 3);
   f32x4 o[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -291,6 +313,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
     for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(Ob + 16 * dt + 4 * g, o[dt] * inv_l);
     if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Tq + i] = tmax + __logf(psum);
   }
+  IMT_STAMP(p.trace, 4);
 }
 
 // =========================================================================================== backward: dQ
@@ -546,22 +569,39 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
   const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)b * p.Tq * p.ldo + h * DH;
 
   // ---- phase 0
+  // every global load of the kernel is requested here, unconditionally (clamped rows, a valid stand-in address for an
+  // absent mask) and before the first use: one memory round trip in front of the barrier instead of one per load
+  IMT_STAMP(p.trace, 0);
+  const int k0 = 16 * wave;
+  const int j = k0 + r;  // this lane's key (phase 1)
+  frag_t kf[NS], vf[NS];
+  bool key_ok;
   {
-    constexpr int CPR = RB / 16;
-    for (int q = threadIdx.x; q < 128 * CPR; q += 512) {
-      const int tr = q / CPR, c = q % CPR;
-      u32x4 vq = {0u, 0u, 0u, 0u}, vo = {0u, 0u, 0u, 0u};
-      if (tr < p.Tq) {
-        vq = *reinterpret_cast<const u32x4*>(Qb + (int64_t)tr * p.ldq + c * 8);
-        vo = *reinterpret_cast<const u32x4*>(dOb + (int64_t)tr * p.lddo + c * 8);
-      }
-      *reinterpret_cast<u32x4*>(Qs + tile_off<RB>(tr, c)) = vq;
-      *reinterpret_cast<u32x4*>(dOs + tile_off<RB>(tr, c)) = vo;
+    constexpr int CPR = RB / 16, NIT = 128 * CPR / 512;
+    u32x4 vq[NIT], vo[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = threadIdx.x + it * 512, tr = min(q / CPR, p.Tq - 1), c = q % CPR;
+      vq[it] = *reinterpret_cast<const u32x4*>(Qb + (int64_t)tr * p.ldq + c * 8);
+      vo[it] = *reinterpret_cast<const u32x4*>(dOb + (int64_t)tr * p.lddo + c * 8);
     }
     const int i = 16 * wave + r;  // delta / lse of this wave's 16 query rows
     frag_t of[NS], dof[NS];
     load_row_frags<T, DH>(of, Ob, p.ldo, 16 * wave, p.Tq);
     load_row_frags<T, DH>(dof, dOb, p.lddo, 16 * wave, p.Tq);
+    load_row_frags<T, DH>(kf, Kb, p.ldk, k0, p.Tk);
+    load_row_frags<T, DH>(vf, Vb, p.ldv, k0, p.Tk);
+    const float lse_v = p.lse[((int64_t)b * p.H + h) * p.Tq + min(i, p.Tq - 1)];
+    const uint8_t* qmp = p.query_mask ? p.query_mask + (int64_t)b * p.Tq + min(i, p.Tq - 1) : reinterpret_cast<const uint8_t*>(Qb);
+    const uint8_t* kmp = p.key_mask ? p.key_mask + (int64_t)b * p.Tk + min(j, p.Tk - 1) : reinterpret_cast<const uint8_t*>(Kb);
+    const uint8_t qmv = *qmp, kmv = *kmp;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = threadIdx.x + it * 512, tr = q / CPR, c = q % CPR;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(Qs + tile_off<RB>(tr, c)) = (tr < p.Tq) ? vq[it] : z;
+      *reinterpret_cast<u32x4*>(dOs + tile_off<RB>(tr, c)) = (tr < p.Tq) ? vo[it] : z;
+    }
     float d = 0.f;
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks)
@@ -571,17 +611,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
     d += __shfl_xor(d, 32, 64);
     if (g == 0) {
       delta_s[i] = d;
-      lse_s[i] = p.lse[((int64_t)b * p.H + h) * p.Tq + (i < p.Tq ? i : 0)];
-      qmask_s[i] = (i < p.Tq && p.query_mask) ? p.query_mask[(int64_t)b * p.Tq + i] : (uint8_t)1;
+      lse_s[i] = lse_v;
+      qmask_s[i] = (i < p.Tq && p.query_mask) ? qmv : (uint8_t)1;
     }
+    key_ok = (j < p.Tk) ? (p.key_mask ? (kmv != 0) : true) : false;
   }
-  const int k0 = 16 * wave;
-  const int j = k0 + r;  // this lane's key (phase 1)
-  frag_t kf[NS], vf[NS];
-  load_row_frags<T, DH>(kf, Kb, p.ldk, k0, p.Tk);
-  load_row_frags<T, DH>(vf, Vb, p.ldv, k0, p.Tk);
-  const bool key_ok = (j < p.Tk) ? (p.key_mask ? (p.key_mask[(int64_t)b * p.Tk + j] != 0) : true) : false;
   __syncthreads();
+  IMT_STAMP(p.trace, 1);
 
   // ---- phase 1
   f32x4 dk[NDT], dv[NDT];
@@ -652,7 +688,9 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
       Vec4<T>::store(dVb + 16 * dt + 4 * g, dv[dt]);
     }
   }
+  IMT_STAMP(p.trace, 2);
   __syncthreads();  // every wave is done with Q / dO; dS^T is complete
+  IMT_STAMP(p.trace, 3);
   char* Ks = Qs;
 #pragma unroll
   for (int ks = 0; ks < NS; ++ks) *reinterpret_cast<frag_t*>(Ks + tile_off<RB>(k0 + r, 4 * ks + g)) = kf[ks];
@@ -674,7 +712,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
     T* dQb = reinterpret_cast<T*>(p.dQ) + ((int64_t)b * p.Tq + i) * p.lddq + h * DH;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(dQb + 16 * dt + 4 * g, dq[dt] * p.scale);
-  }
+  }  IMT_STAMP(p.trace, 4);
 }
 
 int check_args(const imt_attn_args* a, bool bwd) {
@@ -703,7 +741,7 @@ AttnP make_params(const imt_attn_args* a) {
   p.drop_thresh = dropout_thresh(a->dropout_p);
   p.inv_keep = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
   p.seed = a->dropout_seed;
-  p.dO = a->dO; p.lddo = a->lddo; p.dQ = a->dQ; p.lddq = a->lddq; p.dK = a->dK; p.lddk = a->lddk; p.dV = a->dV; p.lddv = a->lddv;
+  p.dO = a->dO; p.lddo = a->lddo; p.dQ = a->dQ; p.lddq = a->lddq; p.dK = a->dK; p.lddk = a->lddk; p.dV = a->dV; p.lddv = a->lddv; p.trace = nullptr;
   p.delta = a->delta;
   return p;
 }
@@ -727,7 +765,10 @@ template <int DH> int bwd_fused_launch(const AttnP& p, hipStream_t st) {
     attr_set = true;
   }
   ImtProfScope prof("attn_bwd_fused_bf16", 10.0 * work, io, st);
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<DH>), dim3(p.B * p.H), dim3(512), lds, st, p);
+  ImtTrace tr("attn_bwd", p.B * p.H, st);
+  AttnP pt = p;
+  pt.trace = tr.dev;
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<DH>), dim3(p.B * p.H), dim3(512), lds, st, pt);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
@@ -758,8 +799,11 @@ extern "C" int imt_attention_fwd(const imt_attn_args* a, void* stream) {
   if (a->Tq <= 128 && a->Tk <= 128 && a->Tq > 64 && !getenv("IMT_ATTN_NO_SHORT_FWD")) {  // one workgroup per (batch, head)
     const double work = (double)p.B * p.H * p.Tq * p.Tk * a->head_dim;
     ImtProfScope prof("attn_fwd_bf16", 4.0 * work, ((double)p.B * p.H * a->head_dim * 2.0) * (2.0 * p.Tq + 2.0 * p.Tk), st);
-    if (a->head_dim == 32) hipLaunchKernelGGL(attn_fwd_short_kernel<32>, dim3(p.B * p.H), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL(attn_fwd_short_kernel<64>, dim3(p.B * p.H), dim3(512), 0, st, p);
+    ImtTrace tr("attn_fwd", p.B * p.H, st);
+    AttnP pt = p;
+    pt.trace = tr.dev;
+    if (a->head_dim == 32) hipLaunchKernelGGL(attn_fwd_short_kernel<32>, dim3(p.B * p.H), dim3(512), 0, st, pt);
+    else hipLaunchKernelGGL(attn_fwd_short_kernel<64>, dim3(p.B * p.H), dim3(512), 0, st, pt);
     IMT_CHECK_LAUNCH();
     return IMT_OK;
   }

@@ -46,6 +46,50 @@ bool imt_prof_enabled();
 const char* imt_prof_intern(const char* kind, int M, int N, int K);
 void* imt_prof_begin_launch(const char* kind, double flops, double bytes, hipStream_t st);
 void imt_prof_end_launch(void* tok, hipStream_t st);
+// ---------------------------------------------------------------- phase tracing (tuning aid, IMT_TRACE=<kernel kind>)
+// A kernel that takes part gets a device buffer (or nullptr): thread 0 of every workgroup stores wall_clock64() (100 MHz)
+// into trace[8 * blockIdx.x + k] at up to 8 phase boundaries; the host then SYNCHRONISES, and prints the mean length of
+// each phase and the span first-start -> last-end.  Off (nullptr, no sync) unless IMT_TRACE names the kind.
+#include <stdlib.h>
+struct ImtTrace {
+  static constexpr int MAXB = 4096;
+  unsigned long long* dev = nullptr;
+  const char* kind; int blocks; hipStream_t st;
+  ImtTrace(const char* kind_, int blocks_, hipStream_t st_) : kind(kind_), blocks(blocks_), st(st_) {
+    static const char* want = getenv("IMT_TRACE");
+    if (!want || strcmp(want, kind_) != 0 || blocks_ > MAXB) return;
+    static unsigned long long* buf = nullptr;
+    if (!buf && hipMalloc(&buf, MAXB * 8 * sizeof(unsigned long long)) != hipSuccess) return;
+    (void)hipMemsetAsync(buf, 0, MAXB * 8 * sizeof(unsigned long long), st);
+    dev = buf;
+  }
+  ~ImtTrace() {
+    if (!dev) return;
+    (void)hipStreamSynchronize(st);
+    static unsigned long long h[MAXB * 8];
+    (void)hipMemcpy(h, dev, sizeof(unsigned long long) * 8 * blocks, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int last = 0;
+    for (int b = 0; b < blocks; ++b)
+      for (int k = 0; k < 8; ++k) {
+        const unsigned long long v = h[8 * b + k];
+        if (!v) continue;
+        if (v < t0) t0 = v;
+        if (v > t1) t1 = v;
+        if (k > last) last = k;
+      }
+    for (int b = 0; b < blocks; ++b) {
+      unsigned long long prev = h[8 * b];
+      for (int k = 1; k <= last; ++k) { const unsigned long long v = h[8 * b + k]; if (v && prev) { ph[k] += (v - prev) * 0.01; prev = v; } }
+    }
+    fprintf(stderr, "[trace %s] %d workgroups, span %.2f us; mean phases (us):", kind, blocks, (t1 - t0) * 0.01);
+    for (int k = 1; k <= last; ++k) fprintf(stderr, " %.2f", ph[k] / blocks);
+    fprintf(stderr, "\n");
+  }
+};
+#define IMT_STAMP(trace, k) do { if ((trace) && threadIdx.x == 0) (trace)[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+
 struct ImtProfScope {
   void* tok; hipStream_t st;
   ImtProfScope(const char* kind, double flops, double bytes, hipStream_t s)

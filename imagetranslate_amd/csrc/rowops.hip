@@ -20,15 +20,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int row = imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* xr = x + (int64_t)row * d;
-  f32x4 v[NCH];
+  f32x4 v[NCH], gv[NCH], bv[NCH];
   float s = 0.f;
+  // every load of the row is requested up front and unconditionally (columns past d read a clamped address and are
+  // masked where used): a load under a branch makes the compiler drain vmcnt at the join, one round trip per load
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane * 4 + i * 256;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < d) v[i] = Vec4<T>::load(xr + c);
-    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const int c = min(lane * 4 + i * 256, d - 4);
+    v[i] = Vec4<T>::load(xr + c);
+    gv[i] = Vec4<T>::load(gamma + c);
+    bv[i] = Vec4<T>::load(beta + c);
   }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane * 4 + i * 256 < d) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   for (int i = 0; i < NCH; ++i) {
     const int c = lane * 4 + i * 256;
     if (c < d) {
-      const f32x4 g = Vec4<T>::load(gamma + c), b = Vec4<T>::load(beta + c);
+      const f32x4 g = gv[i], b = bv[i];
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -69,15 +74,16 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                      int d, int rows_per_wave, uint32_t y_thresh, float y_inv_keep,
                                                      uint64_t y_seed, T* __restrict__ dx_drop, uint32_t dx_thresh,
-                                                     float dx_inv_keep, uint64_t dx_seed) {
+                                                     float dx_inv_keep, uint64_t dx_seed, unsigned long long* trace) {
   __shared__ float red[2][WPB][NCH * 256];
+  auto stamp = [&](int k) { if (trace && threadIdx.x == 0) trace[blockIdx.x * 8 + k] = wall_clock64(); };  // tuning only
+  stamp(0);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   f32x4 g[NCH], ag[NCH], ab[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane * 4 + i * 256;
-    g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < d) g[i] = Vec4<T>::load(gamma + c);
+    g[i] = Vec4<T>::load(gamma + min(c, d - 4));  // unconditional (clamped): only used under c < d
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -90,24 +96,24 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
     float mub[RB], rsb[RB];
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
-      const int row = row_begin + r0 + k;
-      const bool live = (r0 + k < rows_per_wave) && (row < rows);
-      mub[k] = live ? mean[row] : 0.f;
-      rsb[k] = live ? rstd[row] : 0.f;
+      // NO control flow around these loads (a branch makes the compiler drain vmcnt at its join, which serialises the
+      // batch into one memory round trip per row -- IMT_LN_TRACE: 7.6 us to issue 4 rows): dead rows / columns read a
+      // clamped address instead and are masked where they are used
+      const int row = min(row_begin + r0 + k, rows - 1);
+      mub[k] = mean[row];
+      rsb[k] = rstd[row];
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane * 4 + i * 256;
-        xb[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        db[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live && c < d) {
-          xb[k][i] = Vec4<T>::load(x + (int64_t)row * d + c);
-          db[k][i] = Vec4<T>::load(dy + (int64_t)row * d + c);
-        }
+        const int c = min(lane * 4 + i * 256, d - 4);
+        xb[k][i] = Vec4<T>::load(x + (int64_t)row * d + c);
+        db[k][i] = Vec4<T>::load(dy + (int64_t)row * d + c);
       }
     }
+    if (r0 == 0) stamp(1);
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
       const int row = row_begin + r0 + k;
+      if (r0 == 0 && k == 1) stamp(3);
       if (!((r0 + k < rows_per_wave) && (row < rows))) continue;  // wave-uniform
       const float mu = mub[k], rs = rsb[k];
       float s1 = 0.f, s2 = 0.f;
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
         }
       }
       const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+      if (r0 == 0 && k == 0) stamp(2);
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = lane * 4 + i * 256;
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
       }
     }
   }
+  stamp(5);
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
     atomicAdd(dgamma + c, sg);
     atomicAdd(dbeta + c, sb);
   }
+  stamp(6);
 }
 
 // ------------------------------------------------------------------------------------------- embeddings
@@ -327,11 +336,35 @@ int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float*
   hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, W>), dim3(blocks), dim3(W * 64), 0, st, (const T*)dy, (const T*)x,        \
                      (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),            \
                      yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),                      \
-                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed)
+                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed, trace)
+  // tuning aid (IMT_LN_TRACE=1, synchronises): phase time stamps of every workgroup
+  static const bool want_trace = getenv("IMT_LN_TRACE") != nullptr;
+  static unsigned long long* tbuf = nullptr;
+  unsigned long long* trace = nullptr;
+  if (want_trace && blocks <= 1024) {
+    if (!tbuf) (void)hipMalloc(&tbuf, 1024 * 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(tbuf, 0, 1024 * 8 * sizeof(unsigned long long), st);
+    trace = tbuf;
+  }
   if (wpb == 4) IMT_LN_BWD_LAUNCH(4);
   else if (wpb == 8) IMT_LN_BWD_LAUNCH(8);
   else IMT_LN_BWD_LAUNCH(16);
 #undef IMT_LN_BWD_LAUNCH
+  if (trace) {
+    (void)hipStreamSynchronize(st);
+    static unsigned long long h[1024 * 8];
+    (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t2 = 0;
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < blocks; ++b) { if (h[8 * b] < t0) t0 = h[8 * b]; if (h[8 * b + 6] > t2) t2 = h[8 * b + 6]; }
+    for (int b = 0; b < blocks; ++b) {
+      const unsigned long long* q = h + 8 * b;
+      ph[0] += (q[1] - q[0]) * 0.01; ph[1] += (q[2] - q[1]) * 0.01; ph[2] += (q[3] - q[2]) * 0.01; ph[3] += (q[5] - q[3]) * 0.01;
+      ph[4] += (q[6] - q[5]) * 0.01;
+    }
+    fprintf(stderr, "[ln_bwd trace] rows %d blocks %d: span %.2f us | loads issued %.2f, first row reduced %.2f, first row stored %.2f, other rows %.2f, tail %.2f\n",
+            rows, blocks, (t2 - t0) * 0.01, ph[0] / blocks, ph[1] / blocks, ph[2] / blocks, ph[3] / blocks, ph[4] / blocks);
+  }
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
