@@ -75,11 +75,24 @@ IMT_DEVICE void load_row_frags(typename Frag<T>::type (&f)[DH * sizeof(T) / 64],
   }
 }
 
+// MASK3D = false: the kernel instance for launches without an explicit [B, Tq, Tk] mask -- the per-element test of the
+// pointer is a branch + exec save/restore + wait skeleton around a global load, ~10 scalar instructions per element
+// even when the pointer is null.
+template <bool MASK3D = true>
 IMT_DEVICE bool mask_ok(const AttnP& p, int b, int i, int j, bool key_ok, bool query_ok) {
   bool ok = key_ok && query_ok;
   if (p.causal) ok = ok && (j <= i);
-  if (p.mask3d && i < p.Tq && j < p.Tk) ok = ok && (p.mask3d[((int64_t)b * p.Tq + i) * p.Tk + j] != 0);
+  if (MASK3D) {
+    if (p.mask3d && i < p.Tq && j < p.Tk) ok = ok && (p.mask3d[((int64_t)b * p.Tq + i) * p.Tk + j] != 0);
+  }
   return ok;
+}
+// dropout decision for an element index below 2^32: the same bits as dropout_keep(seed, idx) without the 64-bit index
+// arithmetic and one of its five 32-bit multiplies (quarter rate)
+IMT_DEVICE bool dropout_keep32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx, uint32_t thresh) {
+  uint32_t h = mix32(idx ^ seed_lo);
+  h = mix32(h + seed_hi);
+  return h >= thresh;
 }
 
 // accumulator tiles -> operand fragments of the following product (see mma.hpp, "permuted-K")
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(A
 // Tq, Tk <= 128, bf16: one workgroup (8 waves, 16 queries each) per (batch, head).  K and V are staged ONCE for all
 // 128 queries (the 64-query kernel above stages them once per query tile), and with every key resident the softmax is
 // a single pass: all S^T tiles, one max, one exp/sum, then O^T = V^T P^T -- no running rescale.
-template <int DH>
+template <int DH, bool MASK3D>
 __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
   typedef bf16_t T;
   constexpr int RB = DH * 2, NS = RB / 64, NDT = DH / 16;
@@ -268,10 +281,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
     s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) mma16(s[nt], lds_frag_kcontig<T, RB>(Ks, 16 * nt, 4 * ks), qf[ks]);
+    const uint32_t km4 = *reinterpret_cast<const uint32_t*>(kmask_s + 16 * nt + 4 * g);  // this lane's 4 keys
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = 16 * nt + 4 * g + e;
-      float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_s[j] != 0, query_ok) ? 0.f : -10000.0f);
+      float v = s[nt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, ((km4 >> (8 * e)) & 0xffu) != 0, query_ok) ? 0.f : -10000.0f);
       if (j >= p.Tk) v = -INFINITY;
       s[nt][e] = v;
       tmax = fmaxf(tmax, v);
@@ -285,15 +299,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
   for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float pv = __expf(s[nt][e] - tmax);
+      const float pv = __expf(s[nt][e] - tmax);
       psum += pv;
-      if (p.drop_thresh) {
-        const int j = 16 * nt + 4 * g + e;
-        const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
-        pv = dropout_keep(p.seed, idx, p.drop_thresh) ? pv * p.inv_keep : 0.f;
-      }
       s[nt][e] = pv;
     }
+  if (p.drop_thresh) {  // one uniform branch around all 32 elements (host guarantees B*H*Tq*Tk < 2^32 for this kernel)
+    const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Tq + (uint32_t)i) * (uint32_t)p.Tk + 4 * g;
+    const uint32_t slo = (uint32_t)p.seed, shi = (uint32_t)(p.seed >> 32);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        s[nt][e] = dropout_keep32(slo, shi, row_idx + 16 * nt + e, p.drop_thresh) ? s[nt][e] * p.inv_keep : 0.f;
+  }
   psum += __shfl_xor(psum, 16, 64);
   psum += __shfl_xor(psum, 32, 64);
   IMT_STAMP(p.trace, 3);
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(256, (DH == 64 && sizeof(T) == 2) ? 3 : 2) void att
 //   phase 2: QUERY on the lane (wave w owns queries 16w..): dQ = dS K as a plain K-strided x K-strided product from
 //            LDS (dS^T tile, and K parked into the region Q occupied).
 // Nothing is summed across workgroups; same dropout mask / mask semantics as the kernels above.
-template <int DH>
+template <int DH, bool MASK3D>
 __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
   typedef bf16_t T;
   constexpr int RB = DH * 2, NS = RB / 64, NDT = DH / 16;
@@ -640,23 +658,29 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
           mma16(dp[mt], lds_frag_kcontig<T, RB>(dOt, 16 * mt, 4 * ks), vf[ks]);
         }
       }
+      const uint32_t slo = (uint32_t)p.seed, shi = (uint32_t)(p.seed >> 32);
+      const uint32_t col_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Tq * (uint32_t)p.Tk + (uint32_t)j;  // + i * Tk
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt) {
+        // this lane's 4 consecutive queries: their lse / delta / mask bytes in one LDS read each
+        const int i0 = qt * 64 + 16 * mt + 4 * g;
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + i0), del4 = *reinterpret_cast<const f32x4*>(delta_s + i0);
+        const uint32_t qm4 = *reinterpret_cast<const uint32_t*>(qmask_s + i0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int i = qt * 64 + 16 * mt + 4 * g + e;
-          float v = s[mt][e] * p.scale + (mask_ok(p, b, i, j, key_ok, qmask_s[i] != 0) ? 0.f : -10000.0f);
-          float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_s[i]) : 0.f;
+          const int i = i0 + e;
+          float v = s[mt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, key_ok, ((qm4 >> (8 * e)) & 0xffu) != 0) ? 0.f : -10000.0f);
+          float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse4[e]) : 0.f;
           float dpv = dp[mt][e], pdv = pv;
-          if (p.drop_thresh) {
-            const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
-            const bool keep = dropout_keep(p.seed, idx, p.drop_thresh);
+          if (p.drop_thresh) {  // (host guarantees B*H*Tq*Tk < 2^32 for this kernel)
+            const bool keep = dropout_keep32(slo, shi, col_idx + (uint32_t)i * (uint32_t)p.Tk, p.drop_thresh);
             dpv = keep ? dpv * p.inv_keep : 0.f;
             pdv = keep ? pv * p.inv_keep : 0.f;
           }
           pd[mt][e] = pdv;
-          s[mt][e] = pv * (dpv - delta_s[i]);  // dS[i][j]
+          s[mt][e] = pv * (dpv - del4[e]);  // dS[i][j]
         }
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const frag_t pf = acc_pair_to_frag(pd[2 * u], pd[2 * u + 1]);
@@ -755,20 +779,20 @@ template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
-template <int DH> int bwd_fused_launch(const AttnP& p, hipStream_t st) {
+template <int DH, bool MASK3D> int bwd_fused_launch(const AttnP& p, hipStream_t st) {
   const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
   const double io = ((double)p.B * p.H * DH * 2.0) * (4.0 * p.Tq + 4.0 * p.Tk);
   const int lds = 2 * 128 * DH * 2 + 128 * 256 + 128 * 4 * 2 + 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<DH, MASK3D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   ImtProfScope prof("attn_bwd_fused_bf16", 10.0 * work, io, st);
   ImtTrace tr("attn_bwd", p.B * p.H, st);
   AttnP pt = p;
   pt.trace = tr.dev;
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<DH>), dim3(p.B * p.H), dim3(512), lds, st, pt);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, MASK3D>), dim3(p.B * p.H), dim3(512), lds, st, pt);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
@@ -796,14 +820,20 @@ extern "C" int imt_attention_fwd(const imt_attn_args* a, void* stream) {
   const AttnP p = make_params(a);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == IMT_F32) return a->head_dim == 32 ? fwd_launch<float, 32>(p, st) : fwd_launch<float, 64>(p, st);
-  if (a->Tq <= 128 && a->Tk <= 128 && a->Tq > 64 && !getenv("IMT_ATTN_NO_SHORT_FWD")) {  // one workgroup per (batch, head)
+  const bool idx32 = (double)a->B * a->H * a->Tq * a->Tk < 4294967296.0;  // 32-bit dropout element indices
+  if (a->Tq <= 128 && a->Tk <= 128 && a->Tq > 64 && idx32 && !getenv("IMT_ATTN_NO_SHORT_FWD")) {  // one workgroup per (batch, head)
     const double work = (double)p.B * p.H * p.Tq * p.Tk * a->head_dim;
     ImtProfScope prof("attn_fwd_bf16", 4.0 * work, ((double)p.B * p.H * a->head_dim * 2.0) * (2.0 * p.Tq + 2.0 * p.Tk), st);
     ImtTrace tr("attn_fwd", p.B * p.H, st);
     AttnP pt = p;
     pt.trace = tr.dev;
-    if (a->head_dim == 32) hipLaunchKernelGGL(attn_fwd_short_kernel<32>, dim3(p.B * p.H), dim3(512), 0, st, pt);
-    else hipLaunchKernelGGL(attn_fwd_short_kernel<64>, dim3(p.B * p.H), dim3(512), 0, st, pt);
+    if (a->head_dim == 32) {
+      if (p.mask3d) hipLaunchKernelGGL((attn_fwd_short_kernel<32, true>), dim3(p.B * p.H), dim3(512), 0, st, pt);
+      else          hipLaunchKernelGGL((attn_fwd_short_kernel<32, false>), dim3(p.B * p.H), dim3(512), 0, st, pt);
+    } else {
+      if (p.mask3d) hipLaunchKernelGGL((attn_fwd_short_kernel<64, true>), dim3(p.B * p.H), dim3(512), 0, st, pt);
+      else          hipLaunchKernelGGL((attn_fwd_short_kernel<64, false>), dim3(p.B * p.H), dim3(512), 0, st, pt);
+    }
     IMT_CHECK_LAUNCH();
     return IMT_OK;
   }
@@ -816,7 +846,10 @@ extern "C" int imt_attention_bwd(const imt_attn_args* a, void* stream) {
   const AttnP p = make_params(a);
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == IMT_F32) return a->head_dim == 32 ? bwd_launch<float, 32>(p, st) : bwd_launch<float, 64>(p, st);
-  if (a->Tq <= 128 && a->Tk <= 128 && !getenv("IMT_ATTN_NO_FUSED_BWD"))  // short sequences: one fused kernel
-    return a->head_dim == 32 ? bwd_fused_launch<32>(p, st) : bwd_fused_launch<64>(p, st);
+  const bool idx32 = (double)a->B * a->H * a->Tq * a->Tk < 4294967296.0;  // 32-bit dropout element indices
+  if (a->Tq <= 128 && a->Tk <= 128 && idx32 && !getenv("IMT_ATTN_NO_FUSED_BWD")) {  // short sequences: one fused kernel
+    if (p.mask3d) return a->head_dim == 32 ? bwd_fused_launch<32, true>(p, st) : bwd_fused_launch<64, true>(p, st);
+    return a->head_dim == 32 ? bwd_fused_launch<32, false>(p, st) : bwd_fused_launch<64, false>(p, st);
+  }
   return a->head_dim == 32 ? bwd_launch<bf16_t, 32>(p, st) : bwd_launch<bf16_t, 64>(p, st);
 }
