@@ -113,7 +113,7 @@ struct EpiParams {
   float inv_keep; uint32_t drop_thresh; uint64_t seed;
   float* a_colsum;  // TN only: a_colsum[m] += alpha * sum_k A[k][m]   (bias gradient fused into the dW GEMM)
   int dbg;          // tuning only (tools/gemm_shapes.py): bit0 skip the tile products, bit1 skip the in-loop DMA
-  unsigned long long* trace;  // tuning only (IMT_GEMM_TRACE=1): per-workgroup phase time stamps of the 256-tile kernel
+  unsigned long long* trace;  // tuning only (IMT_TRACE=gemm_ws | gemm_xl): per-workgroup phase time stamps
 };
 
 // ------------------------------------------------------------------------------------------------ tile product
@@ -282,6 +282,7 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
       if (KIND == EM_RESID || KIND == EM_DROP_RESID || KIND == EM_ACC) v += Vec4<T>::cvt(pr[gq]);
       if (KIND == EM_F32_ACC) v += pc[gq];
       if (live) {
+        // (non-temporal stores here, to leave less dirty data for the end-of-kernel write-back: no measurable change)
         if (C32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
         else     Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
       }
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
     int cur = 0;
+    IMT_STAMP(ep.trace, 0);
     for (int i = 0; i < my_tiles; ++i) {
       const int lt = imt_xcd_block(blockIdx.x + i * gridDim.x, tiles);
       const int m0 = (lt / nbx) * BM, n0 = (lt % nbx) * BN;
@@ -654,13 +656,17 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       const bool do_colsum = colsum_kernel && n0 == 0;
       for (int t = 0; t < nt; ++t) {
         asm volatile("s_barrier" ::: "memory");
+        if (i == 0 && t == 0) IMT_STAMP(ep.trace, 1);
         const char* ta = smem + cur * STAGE_BYTES;
         compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
         if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
         cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
       }
+      if (i == 0) IMT_STAMP(ep.trace, 2);
       if (i == my_tiles - 1) epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);  // producers join in
       else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
+      if (i == 0) IMT_STAMP(ep.trace, 3);
+      if (i == my_tiles - 1) IMT_STAMP(ep.trace, 4);
       if (colsum_kernel) cs.flush(epi, ep.a_colsum, m0, M, alpha, do_colsum);
     }
   }
@@ -809,8 +815,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
   const int wmi = wave >> 2, wni = wave & 3, wn = (wni & 1) * 64;
   const bool loads_a = wave < 4;
 
-  auto stamp = [&](int k) { if (ep.trace && threadIdx.x == 0) ep.trace[blockIdx.x * 4 + k] = wall_clock64(); };
-  stamp(0);
+  IMT_STAMP(ep.trace, 0);
   DmaPair<T> dma;
   if (loads_a) dma.template init<A_KC>(A, lda, a_bytes, m0, wave);
   else         dma.template init<B_KC>(B, ldb, b_bytes, n0, wave - 4);
@@ -830,12 +835,12 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (t + 1 < nt) issue((t + 1) & 1, t + 1);
-    if (t == 0) stamp(1);
+    if (t == 0) IMT_STAMP(ep.trace, 1);
     const char* st = smem + (t & 1) * XL_STAGE;
     compute_tile_xl<T, LAYOUT>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
-  stamp(2);
+  IMT_STAMP(ep.trace, 2);
   if (n0 + 256 <= N && !ep.atomic && !ep.accumulate && !ep.resid && !ep.drop_thresh && !(ep.dbg & 8)) {
     const int mw = m0 + 128 * wmi, nw = n0 + 64 * wni;
     bool done = true;
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
       else     epilogue_xl_direct<T, IMT_AUX_DGELU, false, false>(acc, mw, nw, M, ep, alpha);
     }
     else done = false;
-    if (done) { stamp(3); return; }
+    if (done) { IMT_STAMP(ep.trace, 3); return; }
   }
   // ragged edge tiles: the bounds-checked restaged epilogue, one 128 x 128 quadrant at a time
 #pragma unroll 1
@@ -1000,35 +1005,11 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
     const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
     const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
     const int nwg = imt_cdiv(a->M, 256) * imt_cdiv(a->N, 256);
-    static const bool trace = getenv("IMT_GEMM_TRACE") != nullptr;
-    if (trace) {
-      // tuning aid (synchronises!): phase time stamps (100 MHz wall clock) of every workgroup of this launch
-      static unsigned long long* dbuf = nullptr;
-      if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 4 * sizeof(unsigned long long));
-      EpiParams ept = ep;
-      ept.trace = nwg <= 4096 ? dbuf : nullptr;
-      (void)hipMemsetAsync(dbuf, 0, 4096 * 4 * sizeof(unsigned long long), st);
-      hipLaunchKernelGGL(kxl, dim3(nwg), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ept);
-      (void)hipStreamSynchronize(st);
-      static unsigned long long host[4096 * 4];
-      (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
-      unsigned long long t0 = ~0ull, t3 = 0;
-      double fill = 0, loop = 0, epi = 0;
-      int cnt = 0;
-      for (int b = 0; b < nwg && b < 4096; ++b) {
-        const unsigned long long* h = host + 4 * b;
-        if (!h[3]) continue;
-        if (h[0] < t0) t0 = h[0];
-        if (h[3] > t3) t3 = h[3];
-        fill += (h[1] - h[0]) * 0.01; loop += (h[2] - h[1]) * 0.01; epi += (h[3] - h[2]) * 0.01; ++cnt;
-      }
-      unsigned long long smax = 0;
-      for (int b = 0; b < nwg && b < 4096; ++b) if (host[4 * b + 3] && host[4 * b] - t0 > smax) smax = host[4 * b] - t0;
-      if (cnt) fprintf(stderr, "[xl trace] %dx%dx%d: %d full workgroups, first start -> last end %.2f us; latest start +%.2f us; mean fill %.2f loop %.2f epilogue %.2f us\n",
-                       a->M, a->N, a->K, cnt, (t3 - t0) * 0.01, smax * 0.01, fill / cnt, loop / cnt, epi / cnt);
-    } else {
-      hipLaunchKernelGGL(kxl, dim3(nwg), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ep);
-    }
+    ImtTrace tr("gemm_xl", nwg, st);  // IMT_TRACE=gemm_xl: phases = first K tile landed | K loop | epilogue
+    EpiParams ept = ep;
+    ept.trace = tr.dev;
+    hipLaunchKernelGGL(kxl, dim3(nwg), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ept);
+    if (tr.dev) fprintf(stderr, "[gemm_xl %s %dx%dx%d]\n", kind, a->M, a->N, a->K);
   } else if (variant == 5) {
     static bool ws_attr = false;
     auto kws = gemm_ws_kernel<T, LAYOUT>;
@@ -1036,7 +1017,11 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
     const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
     const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
     const int tiles = nbx * nby;
-    hipLaunchKernelGGL(kws, dim3(tiles < 256 ? tiles : 256), dim3(WS_THREADS), WS_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ep);
+    ImtTrace tr("gemm_ws", tiles < 256 ? tiles : 256, st);
+    EpiParams ept = ep;
+    ept.trace = tr.dev;
+    hipLaunchKernelGGL(kws, dim3(tiles < 256 ? tiles : 256), dim3(WS_THREADS), WS_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ept);
+    if (tr.dev) fprintf(stderr, "[gemm_ws %s %dx%dx%d bias %d resid %d drop %d aux %d acc %d]\n", kind, a->M, a->N, a->K, ep.bias != nullptr, ep.resid != nullptr, ep.drop_thresh != 0, ep.aux_mode, ep.accumulate);
   } else if (variant == 3) {
     hipLaunchKernelGGL((gemm_sb_kernel<T, LAYOUT>), grid, dim3(NTHREADS), STAGE_BYTES, st, A, a->lda, B, a->ldb, a->M, a->N, a->K, k_per_split, ep);
   } else if (variant == 2 || variant == 4) {

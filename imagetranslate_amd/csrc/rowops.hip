@@ -76,8 +76,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
                                                      uint64_t y_seed, T* __restrict__ dx_drop, uint32_t dx_thresh,
                                                      float dx_inv_keep, uint64_t dx_seed, unsigned long long* trace) {
   __shared__ float red[2][WPB][NCH * 256];
-  auto stamp = [&](int k) { if (trace && threadIdx.x == 0) trace[blockIdx.x * 8 + k] = wall_clock64(); };  // tuning only
-  stamp(0);
+  IMT_STAMP(trace, 0);  // tuning only (IMT_TRACE=ln_bwd)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   f32x4 g[NCH], ag[NCH], ab[NCH];
 #pragma unroll
@@ -109,11 +108,11 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
         db[k][i] = Vec4<T>::load(dy + (int64_t)row * d + c);
       }
     }
-    if (r0 == 0) stamp(1);
+    if (r0 == 0) IMT_STAMP(trace, 1);
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
       const int row = row_begin + r0 + k;
-      if (r0 == 0 && k == 1) stamp(3);
+      if (r0 == 0 && k == 1) IMT_STAMP(trace, 3);
       if (!((r0 + k < rows_per_wave) && (row < rows))) continue;  // wave-uniform
       const float mu = mub[k], rs = rsb[k];
       float s1 = 0.f, s2 = 0.f;
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
         }
       }
       const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
-      if (r0 == 0 && k == 0) stamp(2);
+      if (r0 == 0 && k == 0) IMT_STAMP(trace, 2);
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = lane * 4 + i * 256;
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
       }
     }
   }
-  stamp(5);
+  IMT_STAMP(trace, 5);
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
     atomicAdd(dgamma + c, sg);
     atomicAdd(dbeta + c, sb);
   }
-  stamp(6);
+  IMT_STAMP(trace, 6);
 }
 
 // ------------------------------------------------------------------------------------------- embeddings
@@ -337,34 +336,12 @@ int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float*
                      (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),            \
                      yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),                      \
                      dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed, trace)
-  // tuning aid (IMT_LN_TRACE=1, synchronises): phase time stamps of every workgroup
-  static const bool want_trace = getenv("IMT_LN_TRACE") != nullptr;
-  static unsigned long long* tbuf = nullptr;
-  unsigned long long* trace = nullptr;
-  if (want_trace && blocks <= 1024) {
-    if (!tbuf) (void)hipMalloc(&tbuf, 1024 * 8 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(tbuf, 0, 1024 * 8 * sizeof(unsigned long long), st);
-    trace = tbuf;
-  }
+  ImtTrace tr("ln_bwd", blocks, st);  // phases: loads issued | first row reduced | first row stored | (unused) | other rows | tail
+  unsigned long long* trace = tr.dev;
   if (wpb == 4) IMT_LN_BWD_LAUNCH(4);
   else if (wpb == 8) IMT_LN_BWD_LAUNCH(8);
   else IMT_LN_BWD_LAUNCH(16);
 #undef IMT_LN_BWD_LAUNCH
-  if (trace) {
-    (void)hipStreamSynchronize(st);
-    static unsigned long long h[1024 * 8];
-    (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
-    unsigned long long t0 = ~0ull, t2 = 0;
-    double ph[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < blocks; ++b) { if (h[8 * b] < t0) t0 = h[8 * b]; if (h[8 * b + 6] > t2) t2 = h[8 * b + 6]; }
-    for (int b = 0; b < blocks; ++b) {
-      const unsigned long long* q = h + 8 * b;
-      ph[0] += (q[1] - q[0]) * 0.01; ph[1] += (q[2] - q[1]) * 0.01; ph[2] += (q[3] - q[2]) * 0.01; ph[3] += (q[5] - q[3]) * 0.01;
-      ph[4] += (q[6] - q[5]) * 0.01;
-    }
-    fprintf(stderr, "[ln_bwd trace] rows %d blocks %d: span %.2f us | loads issued %.2f, first row reduced %.2f, first row stored %.2f, other rows %.2f, tail %.2f\n",
-            rows, blocks, (t2 - t0) * 0.01, ph[0] / blocks, ph[1] / blocks, ph[2] / blocks, ph[3] / blocks, ph[4] / blocks);
-  }
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }

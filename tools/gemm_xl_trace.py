@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Phase time stamps of the 256 x 256-tile GEMM (IMT_GEMM_TRACE=1 makes imt_gemm print them to stderr).  Tools only."""
+"""Phase time stamps of the 256 x 256-tile GEMM (IMT_TRACE=gemm_xl makes imt_gemm print them to stderr).  Tools only."""
 import os
 import sys
-os.environ["IMT_GEMM_TRACE"] = "1"
+os.environ["IMT_TRACE"] = "gemm_xl"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imagetranslate_amd import hip_ops as O  # noqa: E402
