@@ -150,9 +150,10 @@ template <typename T> struct ColSum {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s[e] = 0.f;
   }
-  IMT_DEVICE void add_tile(const char* ta) {
+  // tid: index among the 256 threads that share one 128-column tile (the 256 x 256 kernel has two such groups)
+  IMT_DEVICE void add_tile(const char* ta, int tid = threadIdx.x) {
     constexpr int RSTEP = NTHREADS / G::CPR;  // rows covered per pass
-    const int c = threadIdx.x % G::CPR, r0 = threadIdx.x / G::CPR;
+    const int c = tid % G::CPR, r0 = tid / G::CPR;
 #pragma unroll
     for (int i = 0; i < G::BK / RSTEP; ++i) {
       const int row = r0 + i * RSTEP;
@@ -162,20 +163,20 @@ template <typename T> struct ColSum {
     }
   }
   // reduce over the threads that share a chunk column, then one atomic per column
-  IMT_DEVICE void flush(char* smem, float* out, int m0, int M, float alpha, bool active = true) {
+  IMT_DEVICE void flush(char* smem, float* out, int m0, int M, float alpha, bool active = true, int tid = threadIdx.x) {
     constexpr int RSTEP = NTHREADS / G::CPR;
     float* red = reinterpret_cast<float*>(smem);  // [RSTEP][128]
-    const int c = threadIdx.x % G::CPR, r0 = threadIdx.x / G::CPR;
+    const int c = tid % G::CPR, r0 = tid / G::CPR;
     __syncthreads();
     if (active) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) red[r0 * 128 + c * EPC + e] = s[e];
     }
     __syncthreads();
-    if (active && threadIdx.x < 128) {
+    if (active && tid < 128) {
       float t = 0.f;
-      for (int j = 0; j < RSTEP; ++j) t += red[j * 128 + threadIdx.x];
-      if (m0 + (int)threadIdx.x < M) atomicAdd(out + m0 + threadIdx.x, t * alpha);
+      for (int j = 0; j < RSTEP; ++j) t += red[j * 128 + tid];
+      if (m0 + tid < M) atomicAdd(out + m0 + tid, t * alpha);
     }
   }
 };
@@ -828,6 +829,12 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // (no K-order rotation: measured no gain here, and the same K order keeps results bit-identical to the other kernels)
+  // TN weight gradients: the fused bias gradient (column sums of the K-strided A tiles) -- threads 0-255 own the first
+  // 128-column sub-tile, 256-511 the second; only the workgroups of the first tile column take part
+  ColSum<T> cs;
+  cs.clear();
+  const bool do_colsum = (LAYOUT == IMT_TN) && ep.a_colsum && n0 == 0;
+  const int half = threadIdx.x >> 8, ht = threadIdx.x & 255;
   if (nt > 0) issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     // my eight pieces of tile t have landed; the barrier publishes everyone's and proves that the other stage (read
@@ -838,6 +845,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
     if (t == 0) IMT_STAMP(ep.trace, 1);
     const char* st = smem + (t & 1) * XL_STAGE;
     compute_tile_xl<T, LAYOUT>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
+    if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(st + half * TILE_BYTES, ht);
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
   IMT_STAMP(ep.trace, 2);
@@ -859,7 +867,11 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
       else     epilogue_xl_direct<T, IMT_AUX_DGELU, false, false>(acc, mw, nw, M, ep, alpha);
     }
     else done = false;
-    if (done) { IMT_STAMP(ep.trace, 3); return; }
+    if (done) {
+      IMT_STAMP(ep.trace, 3);
+      if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem + half * 16384, ep.a_colsum, m0 + 128 * half, M, alpha, true, ht);
+      return;
+    }
   }
   // ragged edge tiles: the bounds-checked restaged epilogue, one 128 x 128 quadrant at a time
 #pragma unroll 1
@@ -870,6 +882,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
     if (wmi == qm && (wni >> 1) == qn) epilogue<T, XL_THREADS, true, 128>(acc, smem, mq, nq, 0, wn, M, N, ep, alpha);
     else                               epilogue<T, XL_THREADS, false, 128>(acc, smem, mq, nq, 0, wn, M, N, ep, alpha);
   }
+  if (LAYOUT == IMT_TN && do_colsum) cs.flush(smem + half * 16384, ep.a_colsum, m0 + 128 * half, M, alpha, true, ht);
 }
 
 // ------------------------------------------------------------------------------------------------ grouped weight gradients
@@ -1132,12 +1145,15 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     if (!no_xl && pipe_ok && splits == 1 && a->layout != IMT_TN && !a->a_colsum && a->K < 1024 &&
         (tiles256 >= 512 || (tiles256 >= 224 && (a->aux_mode == IMT_AUX_DGELU || a->resid))))
       variant = 6;
+    // a weight gradient with about one 256-tile per CU and a long K (the vocabulary projection's dW: 30000 x 512 x 8128)
+    static const bool no_xl_tn = getenv("IMT_GEMM_NO_XL_TN") != nullptr;
+    if (!no_xl && !no_xl_tn && pipe_ok && splits == 1 && a->layout == IMT_TN && tiles256 >= 224 && tiles256 <= 256 && a->K >= 2048) variant = 6;
     // data-parallel knob (off by default): when a collective's kernels hold some CUs, a persistent
     // launch of exactly one tile per CU needs a full second round; three small workgroups per CU degrade gracefully
     static const bool prefer_small = getenv("IMT_GEMM_SHARE_CUS") != nullptr;
     if (prefer_small && variant == 5 && a->layout != IMT_TN && tiles > 192 && tiles <= 256 && a->K < 1024) variant = 3;
   }
-  if (variant == 6 && (!pipe_ok || splits > 1 || a->a_colsum)) variant = 3;
+  if (variant == 6 && (!pipe_ok || splits > 1 || (a->a_colsum && a->layout != IMT_TN))) variant = 3;
   if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;
   if (variant == 5 && (!pipe_ok || splits > 1)) variant = 3;
   EpiParams ep;

@@ -239,7 +239,8 @@ def test_gemm_tn_fused_bias_gradient(cuda, dtype):
     from imagetranslate_amd import hip_ops as O
     g = torch.Generator().manual_seed(12)
     for (tokens, out_f, in_f, sk, force) in [(512, 200, 136, 1, False), (512, 200, 136, 4, False), (300, 264, 72, 1, True),
-                                             (1024, 1000, 128, 2, False)]:
+                                             (1024, 1000, 128, 2, False), (512, 200, 136, 1, 5), (512, 200, 136, 1, 6),
+                                             (1024, 1000, 392, 1, 6)]:  # 5 / 6: persistent and 256-tile kernels
         dy, dyf = _mk((tokens, out_f), dtype, cuda, 1.0, g)
         x, xf = _mk((tokens, in_f), dtype, cuda, 1.0, g)
         gw0 = torch.randn((out_f, in_f), generator=g); gb0 = torch.randn(out_f, generator=g)
