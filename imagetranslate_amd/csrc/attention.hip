@@ -42,21 +42,13 @@ struct AttnP {
 template <typename T, int DH>
 IMT_DEVICE void stage_tile(char* tile, const T* base, int64_t ld, int row0, int nrows) {
   constexpr int RB = DH * sizeof(T), CPR = RB / 16, EPC = 16 / sizeof(T);
-  // loads first and unconditional (rows past the end read row nrows-1 and are zeroed by a select): a load under a
-  // branch merges with the zero through a phi, and the copy at the join drains vmcnt -- one round trip per load
-  constexpr int NIT = 64 * CPR / 256;
-  static_assert(64 * CPR % 256 == 0, "tile chunks must divide evenly over 256 threads");
-  u32x4 v[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int q = threadIdx.x + it * 256, tr = q / CPR, c = q % CPR;
-    v[it] = *reinterpret_cast<const u32x4*>(base + (int64_t)min(row0 + tr, nrows - 1) * ld + c * EPC);
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int q = threadIdx.x + it * 256, tr = q / CPR, c = q % CPR;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(tile + tile_off<RB>(tr, c)) = (row0 + tr < nrows) ? v[it] : z;
+  // (Kept as a loop with the load under its bounds test: hoisting all loads of a tile into registers, as the short-sequence
+  // kernels do in their prologues, costs the register-bound dK/dV kernel 200 spilled registers -- C4 2.1 -> 2.8 ms.)
+  for (int q = threadIdx.x; q < 64 * CPR; q += 256) {
+    const int tr = q / CPR, c = q % CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + tr < nrows) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + tr) * ld + c * EPC);
+    *reinterpret_cast<u32x4*>(tile + tile_off<RB>(tr, c)) = v;
   }
 }
 

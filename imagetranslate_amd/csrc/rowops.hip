@@ -208,25 +208,57 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         float* __restrict__ dword, float* __restrict__ dpos,
                                                         float* __restrict__ dtype_tab, int n_tokens, int seq_len, int d,
                                                         int64_t pad_id, int tokb) {
-  const int n0 = imt_xcd_block(blockIdx.x, gridDim.x) * tokb;
-  const int n1 = min(n_tokens, n0 + tokb);
+  // Token set of this workgroup.  Default positions (pos = n % seq_len, tokens laid out [sentences][seq_len]): the tokb
+  // tokens are the SAME position of tokb consecutive sentences, so the position-table gradient is summed in a register
+  // and costs one atomic per column and workgroup instead of one per token (the kernel runs at the atomic rate of the
+  // memory side: two atomics per element before, ~1.06 now).  Explicit position ids (MASS): tokb consecutive tokens.
+  const bool posmajor = (pos_ids == nullptr) && (n_tokens % seq_len == 0);
+  const int nsent = n_tokens / seq_len;
+  int first, stride, count, p_own = 0;
+  if (posmajor) {
+    p_own = blockIdx.x % seq_len;
+    const int s0 = (blockIdx.x / seq_len) * tokb;
+    first = s0 * seq_len + p_own; stride = seq_len; count = min(tokb, nsent - s0);
+  } else {
+    first = imt_xcd_block(blockIdx.x, gridDim.x) * tokb; stride = 1; count = min(tokb, n_tokens - first);
+  }
+  if (count <= 0) return;
   for (int c = threadIdx.x; c < d; c += 256) {
-    float tacc[NT_REG];
+    float tacc[NT_REG], pacc = 0.f;
 #pragma unroll
     for (int k = 0; k < NT_REG; ++k) tacc[k] = 0.f;
-    for (int n = n0; n < n1; ++n) {
-      const float v = to_f32<T>(dsum[(int64_t)n * d + c]);
-      const int64_t wi = ids[n];
-      const int64_t pi = pos_ids ? pos_ids[n] : (int64_t)(n % seq_len);
-      const int64_t ti = type_ids ? type_ids[n] : 0;
-      if (wi != pad_id) atomicAdd(dword + wi * d + c, v);
-      atomicAdd(dpos + pi * d + c, v);
-      bool hit = false;
+    // four tokens per trip, their loads requested together and unconditionally (clamped)
+    for (int kb = 0; kb < count; kb += 4) {
+      float vb[4];
+      int64_t wb[4], pb[4], tb[4];
+      const int64_t* pp = pos_ids ? pos_ids : ids;    // a valid stand-in address; the value is replaced below
+      const int64_t* tp = type_ids ? type_ids : ids;
 #pragma unroll
-      for (int k = 0; k < NT_REG; ++k)
-        if (ti == k) { tacc[k] += v; hit = true; }
-      if (!hit) atomicAdd(dtype_tab + ti * d + c, v);
+      for (int k = 0; k < 4; ++k) {
+        const int n = first + min(kb + k, count - 1) * stride;
+        vb[k] = to_f32<T>(dsum[(int64_t)n * d + c]);
+        wb[k] = ids[n];
+        pb[k] = pp[n];
+        tb[k] = tp[n];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (kb + k >= count) break;
+        const int n = first + (kb + k) * stride;
+        const float v = vb[k];
+        const int64_t wi = wb[k];
+        const int64_t ti = type_ids ? tb[k] : 0;
+        if (wi != pad_id) atomicAdd(dword + wi * d + c, v);
+        if (posmajor) pacc += v;
+        else atomicAdd(dpos + (pos_ids ? pb[k] : (int64_t)(n % seq_len)) * d + c, v);
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < NT_REG; ++q)
+          if (ti == q) { tacc[q] += v; hit = true; }
+        if (!hit) atomicAdd(dtype_tab + ti * d + c, v);
+      }
     }
+    if (posmajor) atomicAdd(dpos + (int64_t)p_own * d + c, pacc);
 #pragma unroll
     for (int k = 0; k < NT_REG; ++k)
       if (tacc[k] != 0.f) atomicAdd(dtype_tab + (int64_t)k * d + c, tacc[k]);
@@ -416,7 +448,8 @@ extern "C" int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_i
   IMT_CHECK_ARG(ids && dsum && dword && dpos && dtype_tab, "embed_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int tokb = 16;
-  dim3 grid(imt_cdiv(n_tokens, tokb));
+  const bool posmajor = (pos_ids == nullptr) && (n_tokens % seq_len == 0);  // must match the kernel's own test
+  dim3 grid(posmajor ? seq_len * imt_cdiv(n_tokens / seq_len, tokb) : imt_cdiv(n_tokens, tokb));
   ImtProfScope prof("embed_bwd", 0.0, (double)n_tokens * d * ((dtype == IMT_BF16 ? 2 : 4) + 16.0), st);
   if (dtype == IMT_F32)
     hipLaunchKernelGGL((embed_bwd_kernel<float, 4>), grid, dim3(256), 0, st, ids, pos_ids, type_ids, (const float*)dsum,

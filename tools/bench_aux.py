@@ -22,7 +22,12 @@ def timed(step, warmup=5, steps=20):
     for _ in range(steps):
         n = step()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps, n
+    sec = (time.perf_counter() - t0) / steps
+    if "--breakdown" in sys.argv:  # per-kernel-kind table of the library's launch timer, to stderr
+        from bench import profile_pass
+        for r in profile_pass(step)[:14]:
+            print("    %-28s %4d launches %8.3f ms/step %7.1f TFLOP/s" % (r["kind"], r["launches"], r["ms"], r["flops"] / max(r["ms"], 1e-9) / 1e9), file=sys.stderr)
+    return sec, n
 
 
 def c3():
