@@ -54,11 +54,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(imt_attn_decode_args a
     float k[UNR][8], v[UNR][8];
     int jj[UNR];
     int64_t off[UNR];
+    uint8_t mk[UNR];
+    // slot and mask lookups are unconditional loads (an absent table reads a valid stand-in address and the value is
+    // replaced by a select): a load under a branch drains vmcnt at the join, and the mask byte used to be fetched
+    // inside the dependent softmax chain below -- one exposed latency per key group
+    const int32_t* slot_p = a.slots ? a.slots + (int64_t)r * a.ld_slots : reinterpret_cast<const int32_t*>(a.Q);
+    const uint8_t* mask_p = a.key_mask ? a.key_mask + (int64_t)sent * a.ld_mask : reinterpret_cast<const uint8_t*>(a.Q);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = j0 + u * G + g;
       jj[u] = j < a.n_keys ? j : a.n_keys - 1;
-      const int64_t row = a.slots ? a.slots[(int64_t)r * a.ld_slots + jj[u]] : sent;
+      const int32_t sv = slot_p[a.slots ? jj[u] : 0];
+      mk[u] = mask_p[a.key_mask ? jj[u] : 0];
+      const int64_t row = a.slots ? (int64_t)sv : (int64_t)sent;
       off[u] = row * a.ld_row + (int64_t)jj[u] * a.ld_pos;
     }
 #pragma unroll
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(imt_attn_decode_args a
 #pragma unroll
       for (int x = 1; x < CH; x <<= 1) s += __shfl_xor(s, x, 64);
       s *= a.scale;
-      if (a.key_mask && !a.key_mask[(int64_t)sent * a.ld_mask + jj[u]]) s += -10000.0f;
+      if (a.key_mask && !mk[u]) s += -10000.0f;
       if (valid) {
         const float mn = fmaxf(m, s);
         const float corr = __expf(m - mn), p = __expf(s - mn);  // exp(-inf) == 0 on the first key
