@@ -4,9 +4,9 @@ with a `per_kind` table keyed by the profiler kinds bench.py reports (gemm_<vari
 import json, re, sys
 
 raw = json.load(open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_traffic.json"))
-VAR = {"gemm_kernel": "dbuf", "gemm_pipe_kernel": "dma", "gemm_sb_kernel": "sbuf", "gemm_ws_kernel": "ws"}
+VAR = {"gemm_kernel": "dbuf", "gemm_pipe_kernel": "dma", "gemm_sb_kernel": "sbuf", "gemm_ws_kernel": "ws", "gemm_xl_kernel": "xl"}
 LAY = {"0": "nt", "1": "nn", "2": "tn"}
-OTHER = [("gemm_grouped_tn_kernel", "gemm_bf16_tn_grouped"), ("attn_bwd_fused_kernel", "attn_bwd_fused_bf16"), ("attn_fwd_kernel", "attn_fwd_bf16"),
+OTHER = [("gemm_grouped_tn_kernel", "gemm_bf16_tn_grouped"), ("attn_bwd_fused_kernel", "attn_bwd_fused_bf16"), ("attn_fwd_kernel", "attn_fwd_bf16"), ("attn_fwd_short_kernel", "attn_fwd_bf16"),
          ("ln_bwd_kernel", "layernorm_bwd"), ("ln_fwd_kernel", "layernorm_fwd"), ("clip_adam_kernel", "clip_adam"),
          ("xent_fused", "xent_fused"), ("sumsq_kernel", "grad_sumsq"), ("embed_bwd_kernel", "embed_bwd"), ("embed_fwd_kernel", "embed_fwd")]
 
