@@ -46,6 +46,16 @@ struct StackWs {
   void* d_qkv;                       // [N,3d]
   void* d_q;                         // [N,d]   cross-attention query gradient
   void* d_kv;                        // [Nk,2d]
+  void* d_emb;                       // [N,d]  gradient w.r.t. the embedding sum (its own buffer: see below)
+  // The seven kinds of buffer above exist TWICE (even / odd layers): the weight-gradient launch of layer l may run on
+  // the side stream while layer l-1 already writes its own dy operands (imt_stack_backward); use_scratch(l) points the
+  // fields above at the set of layer l.
+  struct Scratch { void* dpre[3]; void* ddrop[3]; void* d_ctx; void* d_ff; void* d_qkv; void* d_q; void* d_kv; } scr[2];
+  void use_scratch(int l) {
+    const Scratch& z = scr[l & 1];
+    for (int i = 0; i < 3; ++i) { dpre[i] = z.dpre[i]; ddrop[i] = z.ddrop[i]; }
+    d_ctx = z.d_ctx; d_ff = z.d_ff; d_qkv = z.d_qkv; d_q = z.d_q; d_kv = z.d_kv;
+  }
   void* kv_all; void* d_kv_all;      // [Nk, L*2d] when the cross-attention key|value projections are batched
   float* delta;                      // [B,H,T]
   float* ln_partial;                 // IMT_LN_BWD_WS_FLOATS(d)
@@ -105,12 +115,17 @@ void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, 
     L.out = c.take(N * d * es);
   }
   w.d_run = c.take(N * d * es);
-  for (int i = 0; i < 3; ++i) { w.dpre[i] = c.take(N * d * es); w.ddrop[i] = c.take(N * d * es); }
-  w.d_ctx = c.take(N * d * es);
-  w.d_ff = c.take(N * ff * es);
-  w.d_qkv = c.take(N * 3 * d * es);
-  w.d_q = c.take(N * d * es);
-  w.d_kv = c.take((Nk > 0 ? Nk : 1) * 2 * d * es);
+  for (int k = 0; k < 2; ++k) {
+    StackWs::Scratch& z = w.scr[k];
+    for (int i = 0; i < 3; ++i) { z.dpre[i] = c.take(N * d * es); z.ddrop[i] = c.take(N * d * es); }
+    z.d_ctx = c.take(N * d * es);
+    z.d_ff = c.take(N * ff * es);
+    z.d_qkv = c.take(N * 3 * d * es);
+    z.d_q = c.take(N * d * es);
+    z.d_kv = c.take((Nk > 0 ? Nk : 1) * 2 * d * es);
+  }
+  w.use_scratch(0);
+  w.d_emb = c.take(N * d * es);
   w.delta = (float*)c.take((int64_t)B * m->heads * T * 4);
   w.ln_partial = (float*)c.take(IMT_LN_BWD_WS_FLOATS(d) * 4);
   w.bytes = c.off;
@@ -167,12 +182,31 @@ struct DeferredDW {
     while (sk < 8 && tiles * sk * 2 <= 256 && M / (sk * 2) >= 512) sk *= 2;
     if (M % (c.dtype == IMT_BF16 ? 64 : 32) != 0) { a.split_k = sk; a.accumulate = (sk == 1); }
   }
-  int flush(const Ctx& c) {
-    const int rc = n ? imt_gemm_grouped_tn(list, n, c.st) : IMT_OK;
+  int flush(hipStream_t st) {
+    const int rc = n ? imt_gemm_grouped_tn(list, n, st) : IMT_OK;
     n = 0;
     return rc;
   }
 };
+
+// Side stream for the weight-gradient launches (one process drives one GPU from one thread: plain statics).
+// dW of layer l only has to be complete when the stack's backward returns, and it is bound by operand traffic, while
+// the dX chain of layer l-1 is a string of latency-bound launches: on two streams the hardware runs workgroups of
+// both.  ready[l]: main stream has produced every dy operand of layer l.  done[l]: the side stream has finished dW(l).
+struct SideQueue {
+  hipStream_t st = nullptr;
+  hipEvent_t ready[MAX_LAYERS], done[MAX_LAYERS];
+  bool ok = false;
+  bool init() {
+    if (st) return ok;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = (hipStream_t)1; return ok = false; }
+    for (int i = 0; i < MAX_LAYERS; ++i)
+      if (hipEventCreateWithFlags(&ready[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return ok = false;
+    return ok = true;
+  }
+};
+SideQueue g_side;
 
 uint64_t site_seed(uint64_t base, int layer, int site) { return base + 0x9E3779B97F4A7C15ull * (uint64_t)(layer * 16 + site + 1); }
 
@@ -370,9 +404,17 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   const void* dy = (layer_hi == m->n_layers) ? io->d_out : w.d_run;
   const bool batched = cross_kv_batched(m);
   DeferredDW dw;
+  // weight gradients on the side stream: only when this call covers the whole stack (a data-parallel run calls per layer
+  // and hands each layer's gradients to its all-reduce bucket as soon as the call returns) and IMT_DW_SIDE_STREAM != 0
+  static const bool side_env = !(getenv("IMT_DW_SIDE_STREAM") && atoi(getenv("IMT_DW_SIDE_STREAM")) == 0);
+  const bool side = side_env && layer_lo == 0 && layer_hi == m->n_layers && m->n_layers >= 2 && g_side.init();
+  int last_side = -1;
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const imt_layer_desc& p = m->layers[l];
     LayerWs& L = layers[l];
+    w.use_scratch(l);
+    // this layer writes the scratch set dW(l+2) read from: that launch must be over (it is, by a layer's worth of time)
+    if (side && l + 2 < layer_hi) (void)hipStreamWaitEvent(c.st, g_side.done[l + 2], 0);
     if (l == m->n_layers - 1) L.out = io->out;
     const bool has_cross = m->is_decoder && p.cross_attn.qkv_w >= 0;
     const void* x_in = (l == 0) ? w.x0 : (const void*)layers[l - 1].out;
@@ -386,9 +428,21 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
                         io->d_enc_states, first_cross ? 0 : 1, kv_w_off(m, p), kv_b_off(m, p), dkv_l));
     }
     RC(attn_block_bwd(c, p.self_attn, L.self_attn, w, dw, 2, x_in, B, T, nullptr, 0, self_ms, training, seed, l, 0, w.d_run, nullptr, 0));
-    RC(dw.flush(c));  // all 4 (encoder) / 7 (decoder) weight-gradient GEMMs of this layer: one launch
+    // all 4 (encoder) / 7 (decoder) weight-gradient GEMMs of this layer: one launch
+    if (side) {
+      (void)hipEventRecord(g_side.ready[l], c.st);
+      (void)hipStreamWaitEvent(g_side.st, g_side.ready[l], 0);
+      RC(dw.flush(g_side.st));
+      (void)hipEventRecord(g_side.done[l], g_side.st);
+      last_side = l;
+    } else {
+      RC(dw.flush(c.st));
+    }
     dy = w.d_run;
   }
+  // the gradients are complete, in main-stream order, when this call returns (the encoder stack accumulates into the
+  // self-attention weights it shares with the decoder; the optimizer / all-reduce follow on the main stream)
+  // (joined at the end of this function)
   if (layer_lo == 0 && batched) {
     // every layer has written its dK|dV block: d(encoder states) = d_kv_all [Nk, L*2d] x W_kv [L*2d, d], one product with
     // K = L*2d instead of L accumulating ones
@@ -399,11 +453,13 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   }
   if (layer_lo == 0) {
     const void* dy0 = (m->n_layers == 0) ? io->d_out : dy;
-    RC(imt_layernorm_bwd(c.dtype, dy0, w.emb_sum, c.P(m->emb_ln_g), w.emb_mean, w.emb_rstd, w.dpre[0], c.G(m->emb_ln_g), c.G(m->emb_ln_b), N, d,
+    // (w.d_emb, not a scratch buffer of the layers: dW of layers 0 / 1 may still be reading those on the side stream)
+    RC(imt_layernorm_bwd(c.dtype, dy0, w.emb_sum, c.P(m->emb_ln_g), w.emb_mean, w.emb_rstd, w.d_emb, c.G(m->emb_ln_g), c.G(m->emb_ln_b), N, d,
                          training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), nullptr, 0.f, 0, nullptr, c.st));
-    RC(imt_embed_bwd(c.dtype, io->ids, io->pos_ids, io->type_ids, w.dpre[0], c.G(m->emb_word), c.G(m->emb_pos), c.G(m->emb_type), N, T, d,
+    RC(imt_embed_bwd(c.dtype, io->ids, io->pos_ids, io->type_ids, w.d_emb, c.G(m->emb_word), c.G(m->emb_pos), c.G(m->emb_type), N, T, d,
                      m->pad_id, c.st));
   }
+  if (last_side >= 0) (void)hipStreamWaitEvent(c.st, g_side.done[last_side], 0);
   return IMT_OK;
 }
 
