@@ -9,8 +9,14 @@
  *
  * Conventions
  *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*.
- *   - `stream` is a hipStream_t passed as void*; the library never allocates/frees device memory,
- *     never synchronises the device, keeps no global state; all entry points are re-entrant per stream.
+ *   - `stream` is a hipStream_t passed as void*; the library never allocates/frees device memory and
+ *     never synchronises the device; every result is complete in `stream` order when the call returns to
+ *     the host.  One exception to "no global state": a whole-stack imt_stack_backward forks each layer's
+ *     weight-gradient launch onto ONE library-owned non-blocking side stream (created on first use) and
+ *     joins it back into `stream` with events before it returns -- so a stack backward is not capturable
+ *     into a hipGraph on a single stream unless IMT_DW_SIDE_STREAM=0, and one process drives one GPU from
+ *     one thread (the deployment model of this library).  The tuning aids IMT_TRACE / IMT_PROF do allocate
+ *     and synchronise; they are off unless their environment variable is set.
  *   - return 0 on success, a negative IMT_ERR_* otherwise; imt_last_error() gives a thread-local message.
  *   - dtype: IMT_F32 (parity mode, exact fp32 MFMA/VALU) or IMT_BF16 (bf16 storage, fp32 accumulate).
  *     "T" below means the element type selected by `dtype`.  Gradients of PARAMETERS are always fp32
@@ -291,7 +297,9 @@ int64_t imt_stack_workspace_bytes(const imt_stack_desc* m, int B, int T, int Tk)
 int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, void* stream);
 /* backward over layers [layer_lo, layer_hi) in reverse order (layer_hi == n_layers first); the embedding
  * backward runs when layer_lo == 0.  Splitting lets the caller launch gradient all-reduce buckets between
- * segments (RCCL on a side stream).  Parameter gradients are accumulated into m->grads. */
+ * segments (RCCL on a side stream).  Parameter gradients are accumulated into m->grads.  A call that covers
+ * the whole stack (layer_lo == 0, layer_hi == n_layers) runs the per-layer weight-gradient launches on the
+ * library's side stream, concurrently with the next layer's input-gradient chain (joined before return). */
 int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* io, void* ws, int64_t ws_bytes, int layer_lo,
                        int layer_hi, void* stream);
 
