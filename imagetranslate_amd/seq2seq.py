@@ -346,6 +346,8 @@ class Seq2Seq(nn.Module):
         flat = decoder_output.reshape(-1, decoder_output.size(-1))
         if sel_idx is None:
             sel_idx = self._selection(tgt_inputs, tgt_mask)[0]
+        if sel_idx.numel() == flat.shape[0]:
+            return flat  # no padding: the ordered selection of every row is the identity -- no gather / scatter launches
         return _SelectRowsFn.apply(flat, sel_idx)
 
     def _project(self, rows, batch_lang, log_softmax):
