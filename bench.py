@@ -31,6 +31,14 @@ CONFIGS = {
                desc="6L/6L enc-dec d=512 h=8 ff=2048 V=30000, src[64,128] tgt[64,128], synthetic random-token MT"),
     "toy": dict(B=8, S=32, T=32, d=128, heads=4, ff=512, enc=2, dec=2, V=1000,
                 desc="2L/2L d=128 h=4 ff=512 V=1000 (plumbing)"),
+    # side measurements (never the headline): SURVEY 8(d)'s paper-size vocabulary, its ragged-length variant of C1, and
+    # the reference's own default model size (src/seq2seq.py:21-23: d=768, ff=3072, 12 heads, 6 encoder / 3 decoder layers)
+    "c1v60k": dict(B=64, S=128, T=128, d=512, heads=8, ff=2048, enc=6, dec=6, V=60000,
+                   desc="C1 with the paper's 60k vocabulary"),
+    "c1ragged": dict(B=64, S=128, T=128, d=512, heads=8, ff=2048, enc=6, dec=6, V=30000, ragged=True,
+                     desc="C1 with sentence lengths ~ U[64,128] (padding: key masks, non-pad row selection)"),
+    "ref768": dict(B=64, S=128, T=128, d=768, heads=12, ff=3072, enc=6, dec=3, V=30000,
+                   desc="reference default size: 6L/3L d=768 h=12 ff=3072 V=30000, src/tgt [64,128]"),
 }
 
 
@@ -53,6 +61,12 @@ def make_batch(c, seed, device):
     tgt = torch.randint(6, V, (B, T), generator=g)
     src[:, 0], tgt[:, 0] = 5, 6          # language tags first (textprocessor.py:29-30), </s> last
     src[:, -1], tgt[:, -1] = 4, 4
+    if c.get("ragged"):
+        for x, L in ((src, S), (tgt, T)):
+            lens = torch.randint(L // 2, L + 1, (B,), generator=g)
+            for i in range(B):
+                x[i, lens[i] - 1] = 4
+                x[i, lens[i]:] = 0
     b = {"src_texts": src, "dst_texts": tgt, "src_pad_mask": src != 0, "dst_pad_mask": tgt != 0,
          "src_langs": torch.zeros(B, dtype=torch.long), "dst_langs": torch.ones(B, dtype=torch.long)}
     return {k: v.to(device) if k not in ("src_langs", "dst_langs") else v for k, v in b.items()}
