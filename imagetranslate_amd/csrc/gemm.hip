@@ -895,7 +895,7 @@ struct GroupProblem {
   int64_t lda, ldb, ldc, a_bytes, b_bytes;
   int M, N, K, tile_start;
 };
-struct GroupArgs { int count; int total_tiles; float alpha; int pad; GroupProblem p[MAX_GROUP]; };
+struct GroupArgs { int count; int total_tiles; float alpha; int alpha_pad_order /* tuning: 1 = plain workgroup order */; GroupProblem p[MAX_GROUP]; };
 
 // Wave-specialised: waves 0-3 multiply (one per SIMD), waves 4-7 only issue the LDS-DMA of the tiles ahead.  Issuing
 // a 1-KiB DMA piece costs a wave ~100-200 cycles (MI355X_MICROARCH "LDS-DMA piece issue cost"); done by the MFMA waves
@@ -910,14 +910,19 @@ template <typename T>
 __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArgs g) {
   constexpr int BK = TileGeom<T, false>::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-affine tile order: hardware workgroup b runs on XCD b % 8; give each XCD a CONTIGUOUS run of the group's tile list
+  // (row-major per problem), i.e. a few whole tile rows -- its workgroups then share dy / x operand strips through that
+  // XCD's L2.  With the plain order every XCD saw one column and ~24 different rows: 549 MB of fabric traffic per launch
+  // against 160 MB algorithmic, and the kernel ran at the fabric's ~6 TB/s.
+  const int bid = (g.alpha_pad_order == 0) ? imt_xcd_block(blockIdx.x, g.total_tiles) : (int)blockIdx.x;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < MAX_GROUP; ++i)
-    if (i < g.count && (int)blockIdx.x >= g.p[i].tile_start) pi = i;
+    if (i < g.count && bid >= g.p[i].tile_start) pi = i;
   const GroupProblem& P = g.p[pi];
   const int M = P.M, N = P.N, K = P.K;
   const int nbx = (N + BN - 1) / BN;
-  const int local = blockIdx.x - P.tile_start;
+  const int local = bid - P.tile_start;
   const int m0 = (local / nbx) * BM, n0 = (local % nbx) * BN;
   const int nt = K / BK;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1201,6 +1206,8 @@ extern "C" int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* s
   GroupArgs g;
   memset(&g, 0, sizeof(g));
   g.count = count; g.alpha = list[0].alpha;
+  static const bool plain_order = getenv("IMT_GROUPED_PLAIN_ORDER") != nullptr;  // tuning only
+  g.alpha_pad_order = plain_order ? 1 : 0;
   int start = 0;
   double flops = 0, bytes = 0;
   for (int i = 0; i < count; ++i) {
