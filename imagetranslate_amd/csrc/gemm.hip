@@ -771,15 +771,17 @@ IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, int
   }
 }
 
-template <typename T, int LAYOUT>
+template <typename T, int LAYOUT, int HALF = -1>
 IMT_DEVICE void compute_tile_xl(f32x4 (&acc)[8][4], const char* ta, const char* tb, int wn) {
   constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
   typedef TileGeom<T, A_KC> GA;
   typedef TileGeom<T, B_KC> GB;
   typedef typename Frag<T>::type frag_t;
   constexpr int KSTEP = Frag<T>::KSTEP;
+  constexpr int NSTEP = GA::BK / KSTEP;  // HALF = 0 / 1: the first / second half of the tile's K steps only
+  constexpr int S0 = HALF == 1 ? NSTEP / 2 : 0, S1 = HALF == 0 ? NSTEP / 2 : NSTEP;
 #pragma unroll
-  for (int s = 0; s < GA::BK / KSTEP; ++s) {
+  for (int s = S0; s < S1; ++s) {
     frag_t fa[8], fb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -841,10 +843,16 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
     // while multiplying tile t-1) is free for the DMA of tile t+1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    if (t + 1 < nt) issue((t + 1) & 1, t + 1);
+    // Issuing a wave's eight 1-KiB DMA pieces takes it ~0.4 us during which it multiplies nothing (one wave sustains
+    // ~20 GB/s of LDS-DMA, profiles/r01_lds_fill_probe.txt).  Waves w and w+4 share a SIMD: the first issues before its
+    // MFMAs, the second between its two K steps, so each SIMD always has one wave multiplying.
+    const bool issue_now = (t + 1 < nt);
+    if (issue_now && (wave < 4 || (ep.dbg & 64))) issue((t + 1) & 1, t + 1);
     if (t == 0) IMT_STAMP(ep.trace, 1);
     const char* st = smem + (t & 1) * XL_STAGE;
-    compute_tile_xl<T, LAYOUT>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
+    compute_tile_xl<T, LAYOUT, 0>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
+    if (issue_now && wave >= 4 && !(ep.dbg & 64)) issue((t + 1) & 1, t + 1);
+    compute_tile_xl<T, LAYOUT, 1>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
     if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(st + half * TILE_BYTES, ht);
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
