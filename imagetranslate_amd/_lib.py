@@ -169,6 +169,7 @@ SIGNATURES = {
     "imt_xent_fused_fwd_bwd": (c_int, [c_int, _P, c_int64, _P, _P, c_int, c_int, c_float, c_int64, c_float, _P]),
     "imt_scaled_sum": (c_int, [_P, c_int, c_float, _P, _P]),
     "imt_sumsq": (c_int, [_P, c_int64, _P, _P, _P]),
+    "imt_ln_partial_reduce": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "imt_clip_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                               c_int64, c_int, _P]),
     "imt_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),

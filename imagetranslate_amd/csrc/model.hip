@@ -58,7 +58,9 @@ struct StackWs {
   }
   void* kv_all; void* d_kv_all;      // [Nk, L*2d] when the cross-attention key|value projections are batched
   float* delta;                      // [B,H,T]
-  float* ln_partial;                 // IMT_LN_BWD_WS_FLOATS(d)
+  float* ln_partial;                 // [3 * layers + 1][IMT_LN_BWD_WS_FLOATS(d)]: per-XCD dgamma|dbeta partial sums of every
+                                     // LayerNorm site (layer l: 3l = FFN, 3l+1 = cross, 3l+2 = self; last = embeddings)
+  float* ln_site(int site, int d) const { return ln_partial + (int64_t)site * IMT_LN_BWD_WS_FLOATS(d); }
   int64_t bytes;
 };
 
@@ -127,7 +129,7 @@ void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, 
   w.use_scratch(0);
   w.d_emb = c.take(N * d * es);
   w.delta = (float*)c.take((int64_t)B * m->heads * T * 4);
-  w.ln_partial = (float*)c.take(IMT_LN_BWD_WS_FLOATS(d) * 4);
+  w.ln_partial = (float*)c.take((int64_t)(3 * m->n_layers + 1) * IMT_LN_BWD_WS_FLOATS(d) * 4);
   w.bytes = c.off;
 }
 
@@ -263,7 +265,7 @@ int attn_block_bwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, StackWs& sw
   void* d_pre = sw.dpre[slot];
   void* d_dense = (hp > 0.f) ? sw.ddrop[slot] : d_pre;
   RC(imt_layernorm_bwd(c.dtype, dy, w.pre_ln, c.P(p.ln_g), w.mean, w.rstd, d_pre, c.G(p.ln_g), c.G(p.ln_b), N, d, 0.f, 0,
-                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, site0 + 1), nullptr, c.st));
+                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, site0 + 1), sw.ln_site(3 * layer + slot, d), c.st));
   dw.add(c, d_dense, d, w.ctx, d, N, d, d, p.o_w, p.o_b);
   RC(linear_bwd_input(c, d_dense, d, N, d, p.o_w, d, sw.d_ctx, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0));
   imt_attn_args a;
@@ -316,7 +318,7 @@ int ffn_bwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, StackWs& sw, Defe
   void* d_pre = sw.dpre[0];
   void* d_dense = (hp > 0.f) ? sw.ddrop[0] : d_pre;
   RC(imt_layernorm_bwd(c.dtype, dy, w.pre_ln2, c.P(p.ln2_g), w.mean2, w.rstd2, d_pre, c.G(p.ln2_g), c.G(p.ln2_b), N, d, 0.f, 0,
-                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, 8), nullptr, c.st));
+                       (hp > 0.f) ? d_dense : nullptr, hp, site_seed(seed, layer, 8), sw.ln_site(3 * layer, d), c.st));
   dw.add(c, d_dense, d, w.h, ff, N, d, ff, p.ff2_w, p.ff2_b);
   RC(linear_bwd_input(c, d_dense, d, N, d, p.ff2_w, ff, sw.d_ff, ff, nullptr, 0, w.z, IMT_AUX_DGELU, 0));  // dz
   dw.add(c, sw.d_ff, ff, x, d, N, ff, d, p.ff1_w, p.ff1_b);
@@ -404,6 +406,12 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   const void* dy = (layer_hi == m->n_layers) ? io->d_out : w.d_run;
   const bool batched = cross_kv_batched(m);
   DeferredDW dw;
+  // LayerNorm dgamma / dbeta of this call's layers go to per-XCD partial sums (zeroed here, folded into the gradients by
+  // one launch at the end): 256 workgroups per LayerNorm adding straight into the same d gradient addresses cost ~6 us
+  // of serialised atomics per launch
+  const int64_t lnf = IMT_LN_BWD_WS_FLOATS(d);
+  if (layer_hi > layer_lo) (void)hipMemsetAsync(w.ln_site(3 * layer_lo, d), 0, (size_t)(3 * (layer_hi - layer_lo)) * lnf * 4, c.st);
+  if (layer_lo == 0) (void)hipMemsetAsync(w.ln_site(3 * m->n_layers, d), 0, (size_t)lnf * 4, c.st);
   // weight gradients on the side stream: only when this call covers the whole stack (a data-parallel run calls per layer
   // and hands each layer's gradients to its all-reduce bucket as soon as the call returns) and IMT_DW_SIDE_STREAM != 0
   static const bool side_env = !(getenv("IMT_DW_SIDE_STREAM") && atoi(getenv("IMT_DW_SIDE_STREAM")) == 0);
@@ -455,9 +463,26 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
     const void* dy0 = (m->n_layers == 0) ? io->d_out : dy;
     // (w.d_emb, not a scratch buffer of the layers: dW of layers 0 / 1 may still be reading those on the side stream)
     RC(imt_layernorm_bwd(c.dtype, dy0, w.emb_sum, c.P(m->emb_ln_g), w.emb_mean, w.emb_rstd, w.d_emb, c.G(m->emb_ln_g), c.G(m->emb_ln_b), N, d,
-                         training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), nullptr, 0.f, 0, nullptr, c.st));
+                         training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), nullptr, 0.f, 0, w.ln_site(3 * m->n_layers, d), c.st));
     RC(imt_embed_bwd(c.dtype, io->ids, io->pos_ids, io->type_ids, w.d_emb, c.G(m->emb_word), c.G(m->emb_pos), c.G(m->emb_type), N, T, d,
                      m->pad_id, c.st));
+  }
+  {
+    // fold the partial sums of the sites this call covered: [3*layer_lo, 3*layer_hi) and, with layer 0, the embeddings
+    static int64_t g_off[3 * MAX_LAYERS + 1], b_off[3 * MAX_LAYERS + 1];
+    const int first = 3 * layer_lo, emb = 3 * m->n_layers;
+    const int last = (layer_lo == 0) ? emb + 1 : 3 * layer_hi;  // [first, last) -- sites of layers above layer_hi are skipped
+    for (int sidx = first; sidx < last; ++sidx) {
+      g_off[sidx - first] = -1; b_off[sidx - first] = -1;
+      if (sidx == emb) { g_off[sidx - first] = m->emb_ln_g; b_off[sidx - first] = m->emb_ln_b; continue; }
+      const int l = sidx / 3, slot = sidx % 3;
+      if (l >= layer_hi) continue;
+      const imt_layer_desc& p = m->layers[l];
+      if (slot == 0) { g_off[sidx - first] = p.ln2_g; b_off[sidx - first] = p.ln2_b; }
+      else if (slot == 2) { g_off[sidx - first] = p.self_attn.ln_g; b_off[sidx - first] = p.self_attn.ln_b; }
+      else if (m->is_decoder && p.cross_attn.qkv_w >= 0) { g_off[sidx - first] = p.cross_attn.ln_g; b_off[sidx - first] = p.cross_attn.ln_b; }
+    }
+    if (last > first) RC(imt_ln_partial_reduce(w.ln_site(first, d), last - first, d, g_off, b_off, m->grads, c.st));
   }
   if (last_side >= 0) (void)hipStreamWaitEvent(c.st, g_side.done[last_side], 0);
   return IMT_OK;

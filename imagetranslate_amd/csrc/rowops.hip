@@ -74,7 +74,8 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                      int d, int rows_per_wave, uint32_t y_thresh, float y_inv_keep,
                                                      uint64_t y_seed, T* __restrict__ dx_drop, uint32_t dx_thresh,
-                                                     float dx_inv_keep, uint64_t dx_seed, unsigned long long* trace) {
+                                                     float dx_inv_keep, uint64_t dx_seed, float* __restrict__ partial,
+                                                     unsigned long long* trace) {
   __shared__ float red[2][WPB][NCH * 256];
   IMT_STAMP(trace, 0);  // tuning only (IMT_TRACE=ln_bwd)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -166,8 +167,17 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int k = 0; k < WPB; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+    // 256 workgroups adding into the same d addresses serialise at the memory side: ~6 us after the last wave has issued
+    // its atomics (IMT_LN_NO_ATOMICS experiment: 21 -> 15 us per launch).  With `partial` ([8][2][d], zeroed by the caller)
+    // workgroup b adds into copy b % 8 -- its own XCD's -- and imt_ln_partial_reduce folds the copies into the gradients.
+    if (partial) {
+      float* pc = partial + (size_t)(blockIdx.x & 7) * 2 * d;
+      atomicAdd(pc + c, sg);
+      atomicAdd(pc + d + c, sb);
+    } else if (dgamma) {
+      atomicAdd(dgamma + c, sg);
+      atomicAdd(dbeta + c, sb);
+    }
   }
   IMT_STAMP(trace, 6);
 }
@@ -367,7 +377,7 @@ int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float*
   hipLaunchKernelGGL((ln_bwd_kernel<T, NCH, W>), dim3(blocks), dim3(W * 64), 0, st, (const T*)dy, (const T*)x,        \
                      (const T*)gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, d, rpw, dropout_thresh(yp),            \
                      yp > 0.f ? 1.f / (1.f - yp) : 1.f, yseed, (T*)dx_drop, dropout_thresh(dxp),                      \
-                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed, trace)
+                     dxp > 0.f ? 1.f / (1.f - dxp) : 1.f, dxseed, partial, trace)
   ImtTrace tr("ln_bwd", blocks, st);  // phases: loads issued | first row reduced | first row stored | (unused) | other rows | tail
   unsigned long long* trace = tr.dev;
   if (wpb == 4) IMT_LN_BWD_LAUNCH(4);
@@ -401,6 +411,37 @@ extern "C" int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, co
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IMT_F32) IMT_DISPATCH_NCH(ln_fwd_launch, float, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
   IMT_DISPATCH_NCH(ln_fwd_launch, bf16_t, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+}
+
+// grads[g_off[i] + c] += sum_k partials[i][k][0][c], grads[b_off[i] + c] += sum_k partials[i][k][1][c]   (k = 8 copies)
+constexpr int LN_MAX_SITES = 224;
+struct LnReduceArgs { int n, d; int64_t g_off[LN_MAX_SITES], b_off[LN_MAX_SITES]; };
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partials, float* __restrict__ grads,
+                                                                LnReduceArgs a) {
+  const int site = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * a.d || a.g_off[site] < 0) return;  // a negative offset marks an unused slot of the caller's layout
+  const float* p = partials + (size_t)site * 16 * a.d + c;  // [8][2*d]
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sum += p[(size_t)k * 2 * a.d];
+  float* g = grads + (c < a.d ? a.g_off[site] + c : a.b_off[site] + (c - a.d));
+  *g += sum;
+}
+
+extern "C" int imt_ln_partial_reduce(const float* partials, int n_sites, int d, const int64_t* host_dgamma_off,
+                                     const int64_t* host_dbeta_off, float* grads, void* stream) {
+  if (n_sites <= 0) return IMT_OK;
+  IMT_CHECK_ARG(partials && grads && host_dgamma_off && host_dbeta_off && d > 0, "ln_partial_reduce: bad args");
+  IMT_CHECK_ARG(n_sites <= LN_MAX_SITES, "ln_partial_reduce: at most %d sites per call", LN_MAX_SITES);
+  LnReduceArgs a;
+  a.n = n_sites; a.d = d;
+  for (int i = 0; i < n_sites; ++i) { a.g_off[i] = host_dgamma_off[i]; a.b_off[i] = host_dbeta_off[i]; }
+  hipStream_t st = (hipStream_t)stream;
+  ImtProfScope prof("ln_partial_reduce", 0.0, (double)n_sites * 18.0 * d * 4.0, st);
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(imt_cdiv(2 * d, 256), n_sites), dim3(256), 0, st, partials, grads, a);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
 }
 
 extern "C" int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
