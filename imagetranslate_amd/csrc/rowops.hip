@@ -168,10 +168,10 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int k = 0; k < WPB; ++k) { sg += red[0][k][c]; sb += red[1][k][c]; }
     // 256 workgroups adding into the same d addresses serialise at the memory side: ~6 us after the last wave has issued
-    // its atomics (IMT_LN_NO_ATOMICS experiment: 21 -> 15 us per launch).  With `partial` ([8][2][d], zeroed by the caller)
-    // workgroup b adds into copy b % 8 -- its own XCD's -- and imt_ln_partial_reduce folds the copies into the gradients.
+    // its atomics (IMT_LN_NO_ATOMICS experiment: 21 -> 15 us per launch).  With `partial` ([copies][2][d], zeroed by the caller)
+    // workgroup b adds into copy b % copies -- one of its own XCD's (b % 8) -- and imt_ln_partial_reduce folds the copies into the gradients.
     if (partial) {
-      float* pc = partial + (size_t)(blockIdx.x & 7) * 2 * d;
+      float* pc = partial + (size_t)(blockIdx.x & (IMT_LN_PARTIAL_COPIES - 1)) * 2 * d;
       atomicAdd(pc + c, sg);
       atomicAdd(pc + d + c, sb);
     } else if (dgamma) {
@@ -413,7 +413,7 @@ extern "C" int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, co
   IMT_DISPATCH_NCH(ln_fwd_launch, bf16_t, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
 }
 
-// grads[g_off[i] + c] += sum_k partials[i][k][0][c], grads[b_off[i] + c] += sum_k partials[i][k][1][c]   (k = 8 copies)
+// grads[g_off[i] + c] += sum_k partials[i][k][0][c], grads[b_off[i] + c] += sum_k partials[i][k][1][c]   (k over the copies)
 constexpr int LN_MAX_SITES = 224;
 struct LnReduceArgs { int n, d; int64_t g_off[LN_MAX_SITES], b_off[LN_MAX_SITES]; };
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partials, float* __restrict__ grads,
@@ -421,10 +421,10 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __r
   const int site = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= 2 * a.d || a.g_off[site] < 0) return;  // a negative offset marks an unused slot of the caller's layout
-  const float* p = partials + (size_t)site * 16 * a.d + c;  // [8][2*d]
+  const float* p = partials + (size_t)site * IMT_LN_PARTIAL_COPIES * 2 * a.d + c;  // [copies][2*d]
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) sum += p[(size_t)k * 2 * a.d];
+  for (int k = 0; k < IMT_LN_PARTIAL_COPIES; ++k) sum += p[(size_t)k * 2 * a.d];
   float* g = grads + (c < a.d ? a.g_off[site] + c : a.b_off[site] + (c - a.d));
   *g += sum;
 }
@@ -438,7 +438,7 @@ extern "C" int imt_ln_partial_reduce(const float* partials, int n_sites, int d, 
   a.n = n_sites; a.d = d;
   for (int i = 0; i < n_sites; ++i) { a.g_off[i] = host_dgamma_off[i]; a.b_off[i] = host_dbeta_off[i]; }
   hipStream_t st = (hipStream_t)stream;
-  ImtProfScope prof("ln_partial_reduce", 0.0, (double)n_sites * 18.0 * d * 4.0, st);
+  ImtProfScope prof("ln_partial_reduce", 0.0, (double)n_sites * (2.0 * IMT_LN_PARTIAL_COPIES + 2.0) * d * 4.0, st);
   hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(imt_cdiv(2 * d, 256), n_sites), dim3(256), 0, st, partials, grads, a);
   IMT_CHECK_LAUNCH();
   return IMT_OK;

@@ -127,14 +127,15 @@ int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamm
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
                       float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
                       uint64_t dx_dropout_seed, float* partial_ws, void* stream);
-/* partial_ws: NULL, or an [8][2][d] fp32 buffer ZEROED by the caller (IMT_LN_BWD_WS_FLOATS(d) floats).  When given, the
- * per-workgroup column sums are added to copy (workgroup % 8) of it INSTEAD of dgamma / dbeta: 256 workgroups adding
- * into the same d addresses serialise at the memory side (~6 us per launch at rows=8192, d=512), eight copies -- one per
- * XCD -- do not.  imt_ln_partial_reduce then folds any number of such buffers into the gradients in ONE launch:
+/* partial_ws: NULL, or an [IMT_LN_PARTIAL_COPIES][2][d] fp32 buffer ZEROED by the caller (IMT_LN_BWD_WS_FLOATS(d) floats).  When given, the
+ * per-workgroup column sums are added to copy (workgroup % copies) of it INSTEAD of dgamma / dbeta: 256 workgroups adding
+ * into the same d addresses serialise at the memory side (~6 us per launch at rows=8192, d=512), separate copies
+ * (each XCD has its own) do not.  imt_ln_partial_reduce then folds any number of such buffers into the gradients in ONE launch:
  * grads[dgamma_off[i] + c] += sum_k partials[i][k][0][c], likewise dbeta (offsets are HOST arrays of element offsets
  * into `grads`, a negative dgamma offset skips that buffer; at most 224 buffers per call, laid out back to back).  (Also measured, slower: a same-launch "last
  * workgroup of a group sums its group" reduction -- its device-scope release fence writes back the XCD's L2.) */
-#define IMT_LN_BWD_WS_FLOATS(d) (8 * 2 * (int64_t)(d))
+#define IMT_LN_PARTIAL_COPIES 32   /* a multiple of the 8 XCDs: workgroup b -> copy b % 32 stays on XCD b % 8 */
+#define IMT_LN_BWD_WS_FLOATS(d) (IMT_LN_PARTIAL_COPIES * 2 * (int64_t)(d))
 int imt_ln_partial_reduce(const float* partials, int n_sites, int d, const int64_t* host_dgamma_off,
                           const int64_t* host_dbeta_off, float* grads, void* stream);
 
