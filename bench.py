@@ -69,7 +69,12 @@ def make_batch(c, seed, device):
                 x[i, lens[i]:] = 0
     b = {"src_texts": src, "dst_texts": tgt, "src_pad_mask": src != 0, "dst_pad_mask": tgt != 0,
          "src_langs": torch.zeros(B, dtype=torch.long), "dst_langs": torch.ones(B, dtype=torch.long)}
-    return {k: v.to(device) if k not in ("src_langs", "dst_langs") else v for k, v in b.items()}
+    out = {k: v.to(device) if k not in ("src_langs", "dst_langs") else v for k, v in b.items()}
+    # the loader's host-side count of non-pad target positions (the reference: train_image_mt.py:253-256); with it the step
+    # is enqueued without a device->host read.  IMT_BENCH_NO_COUNT=1: let the step read it back from the device instead.
+    if not os.environ.get("IMT_BENCH_NO_COUNT"):
+        out["ntokens"] = int(b["dst_pad_mask"][:, 1:].sum())
+    return out
 
 
 def build_model(c, dtype, device):

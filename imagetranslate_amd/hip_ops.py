@@ -3,6 +3,7 @@ raw device pointers / sizes / the current HIP stream to ``libimt_hip.so`` and re
 the outputs.  PyTorch supplies memory and streams only.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -328,9 +329,12 @@ def beam_step(args: "L.BeamArgs"):
     L.check(L.load().imt_beam_step(ctypes.byref(args), _stream()), "imt_beam_step")
 
 
-def select_plan(mask, ids, col0: int = 1):
+def select_plan(mask, ids, col0: int = 1, count=None):
     """(idx int32 [n], targets int64 [n]) of the positions with mask[b, col0 + t] set; ONE small kernel + one 4-byte
-    device->host read (the row count shapes everything downstream, so this is the step's only synchronisation)."""
+    device->host read (the row count shapes everything downstream, so this is the step's only synchronisation).
+    `count`: the number of set positions when the caller already knows it on the host (a data loader builds the masks on
+    the CPU) -- no read-back, the step is then enqueued without any synchronisation.  It MUST equal
+    mask[:, col0:].sum(); IMT_CHECK_COUNT=1 verifies it (with the read-back)."""
     _req_cuda(mask, ids)
     B, T = ids.shape
     T1 = T - col0
@@ -340,10 +344,15 @@ def select_plan(mask, ids, col0: int = 1):
     n = B * max(T1, 0)
     idx = torch.empty(max(n, 1), dtype=torch.int32, device=ids.device)
     targets = torch.empty(max(n, 1), dtype=torch.int64, device=ids.device)
-    count = torch.empty(1, dtype=torch.int32, device=ids.device)
+    count_dev = torch.empty(1, dtype=torch.int32, device=ids.device)
     if n == 0:
         return idx[:0], targets[:0]
-    L.check(L.load().imt_select_plan(_p(mask), mask.stride(0), _p(ids), ids.stride(0), B, T1, col0, _p(idx), _p(targets), _p(count),
+    L.check(L.load().imt_select_plan(_p(mask), mask.stride(0), _p(ids), ids.stride(0), B, T1, col0, _p(idx), _p(targets), _p(count_dev),
                                      _stream()), "imt_select_plan")
-    k = int(count.item())
+    if count is None or os.environ.get("IMT_CHECK_COUNT"):
+        k = int(count_dev.item())
+        if count is not None and int(count) != k:
+            raise L.ImtError("select_plan: count hint %d but the mask selects %d positions" % (int(count), k))
+    else:
+        k = int(count)
     return idx[:k], targets[:k]

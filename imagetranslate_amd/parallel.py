@@ -120,7 +120,8 @@ def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: f
     from .mass_seq2seq import MassSeq2Seq
     if not isinstance(model, MassSeq2Seq):  # plain Seq2Seq takes explicit masks (src/seq2seq.py:146)
         loss, ntokens = model.loss_fused(batch["src_texts"], batch["dst_texts"], batch["src_pad_mask"],
-                                         batch["dst_pad_mask"], batch["src_langs"], batch["dst_langs"], epsilon=epsilon)
+                                         batch["dst_pad_mask"], batch["src_langs"], batch["dst_langs"], epsilon=epsilon,
+                                         ntokens=batch.get("ntokens"))
     else:  # the trainer's model class derives the masks from the ids (src/mass_seq2seq.py:24-25)
         loss, ntokens = model.loss_fused(src_inputs=batch["src_texts"], tgt_inputs=batch["dst_texts"],
                                          src_langs=batch["src_langs"], tgt_langs=batch["dst_langs"], epsilon=epsilon)

@@ -321,12 +321,12 @@ class Seq2Seq(nn.Module):
         return langs.unsqueeze(-1).expand(-1, width).to(device)
 
     @staticmethod
-    def _selection(tgt_inputs, tgt_mask):
+    def _selection(tgt_inputs, tgt_mask, ntokens=None):
         """(row indices, targets) of the non-pad target positions (src/seq2seq.py:175-177, train_image_mt.py:253-256).
         The row count is data dependent, so this is the step's ONE host synchronisation; the fast path calls it before
         anything is enqueued so that it waits on nothing and the rest of the step is launched without bubbles."""
         if tgt_mask.is_cuda and tgt_inputs.is_cuda and tgt_inputs.dtype == torch.int64 and tgt_mask.dtype in (torch.bool, torch.uint8):
-            return O.select_plan(tgt_mask, tgt_inputs, col0=1)
+            return O.select_plan(tgt_mask, tgt_inputs, col0=1, count=ntokens)
         idx = torch.nonzero(tgt_mask[:, 1:].reshape(-1), as_tuple=False).view(-1)
         return idx.to(torch.int32), tgt_inputs[:, 1:].reshape(-1)[idx]
 
@@ -375,17 +375,19 @@ class Seq2Seq(nn.Module):
         return self._project(rows, batch_lang, log_softmax)
 
     def loss_fused(self, src_inputs, tgt_inputs, src_mask, tgt_mask, src_langs, tgt_langs, epsilon: float = 0.1,
-                   proposals=None):
+                   proposals=None, ntokens=None):
         """Training fast path == ``SmoothedNLLLoss(ignore_index=pad)(self(..., log_softmax=True), targets).mean()``
         with targets = tgt_inputs[:, 1:][tgt_mask[:, 1:]] (src/train_image_mt.py:249-256,282).
-        Returns (loss, ntokens)."""
+        `ntokens`: int(tgt_mask[:, 1:].sum()) when the caller has it on the host (the reference computes it from the
+        batch at train_image_mt.py:253-256; our datasets put it in the batch dict) -- the step then needs no host
+        synchronisation at all.  Returns (loss, ntokens)."""
         device = self.encoder.embeddings.word_embeddings.weight.device
         batch_lang = int(tgt_langs[0])
         src_langs_t = self._lang_grid(src_langs, src_inputs.size(-1), device)
         tgt_langs_t = self._lang_grid(tgt_langs, tgt_inputs.size(-1), device)
         src_inputs, tgt_inputs = src_inputs.to(device), tgt_inputs.to(device)
         src_mask, tgt_mask = src_mask.to(device), tgt_mask.to(device)
-        sel_idx, targets = self._selection(tgt_inputs, tgt_mask)
+        sel_idx, targets = self._selection(tgt_inputs, tgt_mask, ntokens)
         encoder_states = self.encode(src_inputs, src_mask, src_langs_t)[0]
         rows = self._decode(encoder_states, src_mask, tgt_inputs, tgt_mask, tgt_langs_t, batch_lang, proposals=proposals,
                             pad_idx=self.text_processor.pad_token_id(), sel_idx=sel_idx)
