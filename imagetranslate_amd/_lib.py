@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libimt_hip.so")
 
 IMT_F32, IMT_BF16 = 0, 1
 IMT_NT, IMT_NN, IMT_TN = 0, 1, 2
-IMT_AUX_NONE, IMT_AUX_GELU_FWD, IMT_AUX_DGELU = 0, 1, 2
+IMT_AUX_NONE, IMT_AUX_GELU_FWD, IMT_AUX_DGELU, IMT_AUX_SPLITK_WS = 0, 1, 2, 3
 
 
 class GemmArgs(Structure):

@@ -114,6 +114,7 @@ struct EpiParams {
   float* a_colsum;  // TN only: a_colsum[m] += alpha * sum_k A[k][m]   (bias gradient fused into the dW GEMM)
   int dbg;          // tuning only (tools/gemm_shapes.py): bit0 skip the tile products, bit1 skip the in-loop DMA
   unsigned long long* trace;  // tuning only (IMT_TRACE=gemm_ws | gemm_xl): per-workgroup phase time stamps
+  int64_t slab_elems;         // 256-tile kernel, split-K slab mode: C of K split y = C + y * slab_elems (fp32 slabs)
 };
 
 // ------------------------------------------------------------------------------------------------ tile product
@@ -813,7 +814,12 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
   const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
   const int bid = imt_xcd_block(blockIdx.x, nbx * nby);
   const int m0 = (bid / nbx) * 256, n0 = (bid % nbx) * 256;
-  const int nt = K / BK;  // host guarantees whole K tiles
+  // split-K slab mode (gridDim.y > 1): this workgroup multiplies K tiles [kt0, kt0 + nt) into its own fp32 slab
+  const int nt_all = K / BK;  // host guarantees whole K tiles
+  const int per = (nt_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kt0 = (int)blockIdx.y * per;
+  const int nt = max(0, min(per, nt_all - kt0));
+  if (gridDim.y > 1) ep.C = reinterpret_cast<float*>(ep.C) + (int64_t)blockIdx.y * ep.slab_elems;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wmi = wave >> 2, wni = wave & 3, wn = (wni & 1) * 64;
   const bool loads_a = wave < 4;
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
   DmaPair<T> dma;
   if (loads_a) dma.template init<A_KC>(A, lda, a_bytes, m0, wave);
   else         dma.template init<B_KC>(B, ldb, b_bytes, n0, wave - 4);
-  auto issue = [&](int slot, int t) { dma.issue(smem + slot * XL_STAGE + (loads_a ? 0 : 2 * TILE_BYTES), t); };
+  auto issue = [&](int slot, int t) { dma.issue(smem + slot * XL_STAGE + (loads_a ? 0 : 2 * TILE_BYTES), kt0 + t); };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -1031,10 +1037,10 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
     const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
     const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
     const int nwg = imt_cdiv(a->M, 256) * imt_cdiv(a->N, 256);
-    ImtTrace tr("gemm_xl", nwg, st);  // IMT_TRACE=gemm_xl: phases = first K tile landed | K loop | epilogue
+    ImtTrace tr("gemm_xl", splits == 1 ? nwg : 0, st);  // IMT_TRACE=gemm_xl: phases = first K tile landed | K loop | epilogue
     EpiParams ept = ep;
     ept.trace = tr.dev;
-    hipLaunchKernelGGL(kxl, dim3(nwg), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ept);
+    hipLaunchKernelGGL(kxl, dim3(nwg, splits), dim3(XL_THREADS), XL_LDS, st, A, a->lda, a_bytes, B, a->ldb, b_bytes, a->M, a->N, a->K, ept);
     if (tr.dev) fprintf(stderr, "[gemm_xl %s %dx%dx%d]\n", kind, a->M, a->N, a->K);
   } else if (variant == 5) {
     static bool ws_attr = false;
@@ -1074,7 +1080,67 @@ template <typename T> int dispatch(const imt_gemm_args* a, const EpiParams& ep, 
   return IMT_ERR_BAD_ARG;
 }
 
+// C[m][n] = (accumulate ? C[m][n] : 0) + sum_s slab[s][m][n]      (split-K slab mode of the 256-tile kernel)
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_elems, int splits,
+                                                            TC* __restrict__ C, int64_t ldc, int M, int N, int accumulate) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 4-column group index
+  const int n4 = N >> 2;
+  if (q >= (int64_t)M * n4) return;
+  const int m = (int)(q / n4), n = (int)(q % n4) * 4;
+  f32x4 v = Vec4<float>::load(slabs + (int64_t)m * N + n);
+  for (int sidx = 1; sidx < splits; ++sidx) v += Vec4<float>::load(slabs + sidx * slab_elems + (int64_t)m * N + n);
+  TC* c = C + (int64_t)m * ldc + n;
+  if (accumulate) v += Vec4<TC>::load(c);
+  Vec4<TC>::store(c, v);
+}
+
 }  // namespace
+
+// aux_mode IMT_AUX_SPLITK_WS: a product with few output tiles and a very long K (dX through the vocabulary: 8128 x 512 x
+// 30000 has 64 tiles of 256 x 256) runs as split_k K-ranges of 256-tile workgroups, each into its own fp32 slab of the
+// caller's workspace `aux` (split_k * M * N floats), followed by one reduce launch -- no atomics, fixed summation order.
+static int gemm_splitk_slabs(const imt_gemm_args* a, void* stream) {
+  const int bk = (a->dtype == IMT_BF16) ? 64 : 32, es = (a->dtype == IMT_BF16) ? 2 : 4;
+  IMT_CHECK_ARG(a->layout != IMT_TN && a->aux && a->split_k >= 2 && a->split_k <= 16, "imt_gemm: split-K slab mode needs NT/NN, a workspace and 2..16 splits");
+  IMT_CHECK_ARG(!a->bias && !a->resid && a->dropout_p == 0.f && !a->a_colsum && a->N % 4 == 0 && a->K >= 2 * bk * a->split_k,
+                "imt_gemm: split-K slab mode: plain epilogue, N %% 4 == 0, at least two K tiles per split");
+  IMT_CHECK_ARG(a->c_dtype == a->dtype || a->c_dtype == IMT_F32, "imt_gemm: c_dtype must be f32 or dtype");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  imt_gemm_args body = *a;
+  body.aux = nullptr; body.aux_mode = IMT_AUX_NONE;
+  int accumulate = a->accumulate;
+  if (a->K % bk != 0) {  // ragged tail first, as its own small product straight into C
+    const int kb = (a->K / bk) * bk;
+    imt_gemm_args tail = body;
+    tail.split_k = 1; tail.K = a->K - kb;
+    tail.A = reinterpret_cast<const char*>(a->A) + (int64_t)kb * es;                                   // NT / NN: A is [M][K]
+    tail.B = reinterpret_cast<const char*>(a->B) + (a->layout == IMT_NT ? (int64_t)kb : (int64_t)kb * a->ldb) * es;
+    const int rc = imt_gemm(&tail, stream);
+    if (rc != IMT_OK) return rc;
+    body.K = kb; accumulate = 1;
+  }
+  const int64_t a_rows = body.M, b_rows = (body.layout == IMT_NT) ? body.N : body.K;
+  IMT_CHECK_ARG(a_rows * body.lda * es < (1ll << 31) && b_rows * body.ldb * es < (1ll << 31), "imt_gemm: split-K slab mode: operand too large for 32-bit offsets");
+  EpiParams ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = a->aux; ep.ldc = body.N; ep.c_f32 = 1; ep.accumulate = 0;
+  ep.alpha = body.alpha; ep.alpha_dev = body.alpha_dev; ep.inv_keep = 1.0f;
+  ep.slab_elems = (int64_t)body.M * body.N;
+  int rc = (body.dtype == IMT_F32) ? dispatch<float>(&body, ep, body.split_k, body.K, 6, st) : dispatch<bf16_t>(&body, ep, body.split_k, body.K, 6, st);
+  if (rc != IMT_OK) return rc;
+  const int64_t groups = (int64_t)body.M * (body.N / 4);
+  ImtProfScope prof("gemm_splitk_reduce", 0.0, (double)body.M * body.N * (4.0 * body.split_k + 2.0 * es), st);
+  const float* slabs = reinterpret_cast<const float*>(a->aux);
+  if (a->c_dtype == IMT_F32)
+    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(imt_cdiv(groups, 256)), dim3(256), 0, st, slabs, ep.slab_elems, body.split_k,
+                       reinterpret_cast<float*>(a->C), a->ldc, body.M, body.N, accumulate);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(imt_cdiv(groups, 256)), dim3(256), 0, st, slabs, ep.slab_elems, body.split_k,
+                       reinterpret_cast<bf16_t*>(a->C), a->ldc, body.M, body.N, accumulate);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
 
 extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   IMT_CHECK_ARG(a != nullptr, "imt_gemm: null args");
@@ -1104,6 +1170,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   const int c_f32 = (a->c_dtype == IMT_F32);
   IMT_CHECK_ARG(c_f32 || a->c_dtype == a->dtype, "imt_gemm: c_dtype must be f32 or dtype");
   IMT_CHECK_ARG(!a->a_colsum || a->layout == IMT_TN, "imt_gemm: a_colsum is a TN (weight-gradient) option");
+  if (a->aux_mode == IMT_AUX_SPLITK_WS) return gemm_splitk_slabs(a, stream);
   int splits = a->split_k > 1 ? a->split_k : 1;
   const int bk = (a->dtype == IMT_BF16) ? 64 : 32;
   int kps = a->K;

@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _lib as L
-from ._lib import IMT_AUX_DGELU, IMT_AUX_GELU_FWD, IMT_AUX_NONE, IMT_BF16, IMT_F32, IMT_NN, IMT_NT, IMT_TN  # noqa: F401
+from ._lib import IMT_AUX_DGELU, IMT_AUX_GELU_FWD, IMT_AUX_NONE, IMT_AUX_SPLITK_WS, IMT_BF16, IMT_F32, IMT_NN, IMT_NT, IMT_TN  # noqa: F401
 
 
 def dt(t: torch.Tensor) -> int:

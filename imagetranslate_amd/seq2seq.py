@@ -96,9 +96,19 @@ class _FusedXentFn(torch.autograd.Function):
         store = ctx.store
         V, K = ctx.shape
         g = g.float().reshape(1).contiguous()  # upstream scalar stays on the device (no host sync)
-        dx = O.gemm(dlogits, w, O.IMT_NN, alpha_dev=g)
-        gw = store.grad[ctx.wo:ctx.wo + V * K].view(V, K)
         n = dlogits.shape[0]
+        tiles256 = ((n + 255) // 256) * ((K + 255) // 256)
+        if (V >= 16384 and n >= 2048 and K % 4 == 0 and tiles256 <= 128 and dlogits.dtype == torch.bfloat16
+                and os.environ.get("IMT_VOCAB_DX_SPLITK", "1") != "0"):
+            # few output tiles, K = vocabulary: K-ranges of 256-tile workgroups into fp32 slabs + one reduce launch
+            # (8128 x 512 x 30000: 64 tiles x 4 splits fill the chip at the 256-tile rate)
+            splits = max(2, min(8, 256 // tiles256))
+            slabs = torch.empty((splits * n, K), device=dlogits.device, dtype=torch.float32)
+            dx = O.alloc_rows(n, K, dlogits.dtype, dlogits.device)
+            O.gemm(dlogits, w, O.IMT_NN, out=dx, aux=slabs, aux_mode=O.IMT_AUX_SPLITK_WS, split_k=splits, alpha_dev=g)
+        else:
+            dx = O.gemm(dlogits, w, O.IMT_NN, alpha_dev=g)
+        gw = store.grad[ctx.wo:ctx.wo + V * K].view(V, K)
         sk = max(1, min(n // 512, 512 // max(1, ((V + 127) // 128) * ((K + 127) // 128))))
         O.gemm(dlogits, x, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk, alpha_dev=g,
                a_colsum=store.grad[ctx.bo:ctx.bo + V])  # bias gradient fused: dlogits is read once

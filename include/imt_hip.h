@@ -79,6 +79,10 @@ int imt_prof_report(imt_prof_row* rows, int max_kinds);
 #define IMT_AUX_NONE 0
 #define IMT_AUX_GELU_FWD 1
 #define IMT_AUX_DGELU 2
+#define IMT_AUX_SPLITK_WS 3 /* aux = fp32 WORKSPACE of split_k * M * N floats: NT / NN product as split_k K-ranges of 256 x 256-tile
+                               workgroups, each into its own slab, then one reduce launch into C (C += with accumulate; plain
+                               epilogue only: alpha / alpha_dev).  For few output tiles and a very long K (dX through the
+                               vocabulary); fixed summation order, no atomics.  split_k = 2..16. */
 
 typedef struct imt_gemm_args {
   int32_t dtype, layout;

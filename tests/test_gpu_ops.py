@@ -580,3 +580,31 @@ def test_clip_adam_matches_torch(cuda):
         assert_close(p, pr.detach(), 1e-5, "adam step %d" % step)
         assert float(gdev.abs().max()) == 0.0
         assert torch.equal(pb.cpu(), p.cpu().bfloat16())
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_splitk_slab_mode(cuda, dtype, layout):
+    """IMT_AUX_SPLITK_WS: K-ranges of 256-tile workgroups into fp32 slabs + one reduce launch == the plain product, with a
+    ragged K tail, alpha_dev, accumulate, ragged M / N and bf16 or fp32 output (exact on integer data)."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(77)
+    bk = 64 if dtype == torch.bfloat16 else 32
+    for (M, N, K, splits) in [(300, 264, 16 * bk, 4), (520, 128, 9 * bk + 24, 2), (256, 256, 40 * bk, 8)]:
+        A = torch.randint(-2, 3, (M, K), generator=g).float()
+        B = torch.randint(-2, 3, (N, K), generator=g).float()
+        ref = A @ B.t()
+        da = A.to(dtype).to(cuda)
+        db = (B if layout == O.IMT_NT else B.t().contiguous()).to(dtype).to(cuda)
+        slabs = torch.empty(splits * M, N, device=cuda, dtype=torch.float32)
+        out = torch.empty(M, N, device=cuda, dtype=torch.float32)
+        O.gemm(da, db, layout, out=out, aux=slabs, aux_mode=O.IMT_AUX_SPLITK_WS, split_k=splits)
+        assert torch.equal(out.cpu(), ref), (M, N, K, splits)
+        c0 = torch.randint(-4, 5, (M, N), generator=g).float()
+        out = c0.clone().to(cuda)
+        scale = torch.tensor([0.5], device=cuda)
+        O.gemm(da, db, layout, out=out, aux=slabs, aux_mode=O.IMT_AUX_SPLITK_WS, split_k=splits, accumulate=True, alpha_dev=scale)
+        assert torch.equal(out.cpu(), c0 + 0.5 * ref), "accumulate + alpha_dev"
+        outT = torch.empty(M, N, device=cuda, dtype=dtype)
+        O.gemm(da, db, layout, out=outT, aux=slabs, aux_mode=O.IMT_AUX_SPLITK_WS, split_k=splits)
+        assert_close(outT.float(), ref, 1e-6 if dtype == torch.float32 else 8e-3, "compute-dtype output")
