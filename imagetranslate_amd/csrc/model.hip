@@ -415,7 +415,8 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   // weight gradients on the side stream: only when this call covers the whole stack (a data-parallel run calls per layer
   // and hands each layer's gradients to its all-reduce bucket as soon as the call returns) and IMT_DW_SIDE_STREAM != 0
   static const bool side_env = !(getenv("IMT_DW_SIDE_STREAM") && atoi(getenv("IMT_DW_SIDE_STREAM")) == 0);
-  const bool side = side_env && layer_lo == 0 && layer_hi == m->n_layers && m->n_layers >= 2 && g_side.init();
+  // (not while the per-launch event profiler is on: a launch timed next to a concurrent one is not that kernel's time)
+  const bool side = side_env && !imt_prof_enabled() && layer_lo == 0 && layer_hi == m->n_layers && m->n_layers >= 2 && g_side.init();
   int last_side = -1;
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const imt_layer_desc& p = m->layers[l];
