@@ -122,17 +122,35 @@ def layernorm_fwd(x, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0):
     return y, mean, rstd
 
 
+LN_PARTIAL_COPIES = 32  # IMT_LN_PARTIAL_COPIES (include/imt_hip.h)
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, y_dropout_p=0.0, y_dropout_seed=0, want_dx_drop=False,
-                  dx_dropout_p=0.0, dx_dropout_seed=0):
-    _req_cuda(dy, x, gamma, dgamma, dbeta)
+                  dx_dropout_p=0.0, dx_dropout_seed=0, partial_ws=None):
+    """partial_ws: optional ZEROED fp32 [LN_PARTIAL_COPIES, 2, d] buffer -- the column sums go there instead of into
+    dgamma / dbeta (fold with ln_partial_reduce); None = straight atomics into dgamma / dbeta."""
+    _req_cuda(dy, x, gamma, dgamma, dbeta, partial_ws)
     rows, d = x.shape
     dx = torch.empty_like(x)
     dx_drop = torch.empty_like(x) if want_dx_drop else None
-    ws = None  # partial_ws is reserved (include/imt_hip.h)
+    ws = partial_ws
+    if ws is not None:
+        assert ws.dtype == torch.float32 and ws.is_contiguous() and ws.numel() == LN_PARTIAL_COPIES * 2 * d
     L.check(L.load().imt_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                        _p(dbeta), rows, d, y_dropout_p, y_dropout_seed, _p(dx_drop), dx_dropout_p,
                                        dx_dropout_seed, _p(ws), _stream()), "imt_layernorm_bwd")
     return (dx, dx_drop) if want_dx_drop else dx
+
+
+def ln_partial_reduce(partials, grads, dgamma_offsets, dbeta_offsets):
+    """grads[dgamma_offsets[i] + c] += sum over the copies of partials[i, :, 0, c] (likewise dbeta with [i, :, 1, c]);
+    partials: fp32 [n, LN_PARTIAL_COPIES, 2, d]; a negative dgamma offset skips that buffer.  One launch."""
+    _req_cuda(partials, grads)
+    n, copies, two, d = partials.shape
+    assert copies == LN_PARTIAL_COPIES and two == 2 and partials.is_contiguous() and grads.dtype == torch.float32
+    g = (ctypes.c_int64 * n)(*[int(v) for v in dgamma_offsets])
+    b = (ctypes.c_int64 * n)(*[int(v) for v in dbeta_offsets])
+    L.check(L.load().imt_ln_partial_reduce(_p(partials), n, d, g, b, _p(grads), _stream()), "imt_ln_partial_reduce")
 
 
 def embed_fwd(ids, pos_ids, type_ids, word, pos, typ, seq_len):

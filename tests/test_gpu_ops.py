@@ -608,3 +608,32 @@ def test_gemm_splitk_slab_mode(cuda, dtype, layout):
         outT = torch.empty(M, N, device=cuda, dtype=dtype)
         O.gemm(da, db, layout, out=outT, aux=slabs, aux_mode=O.IMT_AUX_SPLITK_WS, split_k=splits)
         assert_close(outT.float(), ref, 1e-6 if dtype == torch.float32 else 8e-3, "compute-dtype output")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_bwd_partial_sums(cuda, dtype):
+    """imt_layernorm_bwd with a partial-sum workspace + imt_ln_partial_reduce == the straight-atomics form: same dx,
+    dgamma / dbeta equal up to summation order, a skipped slot (negative offset) left alone, accumulation onto old values."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(5)
+    rows, d = 1000, 384
+    x, _ = _mk((rows, d), dtype, cuda, 1.0, g)
+    dy, _ = _mk((rows, d), dtype, cuda, 1.0, g)
+    gamma, _ = _mk((d,), dtype, cuda, 1.0, g)
+    beta, _ = _mk((d,), dtype, cuda, 1.0, g)
+    y, mean, rstd = O.layernorm_fwd(x, gamma, beta)
+    grads_ref = torch.randn(4 * d, generator=g).to(cuda)
+    grads = grads_ref.clone()
+    init = grads_ref.clone()
+    dx_ref = O.layernorm_bwd(dy, x, gamma, mean, rstd, grads_ref[d:2 * d], grads_ref[3 * d:4 * d])
+    parts = torch.zeros(3, O.LN_PARTIAL_COPIES, 2, d, device=cuda)
+    parts[1].fill_(7.0)  # a slot the reduce must skip
+    dx = O.layernorm_bwd(dy, x, gamma, mean, rstd, grads[d:2 * d], grads[3 * d:4 * d], partial_ws=parts[2])
+    assert torch.equal(dx, dx_ref)
+    before = grads.clone()
+    assert torch.equal(before, init), "the gradients must be untouched until the reduce"
+    O.ln_partial_reduce(parts, grads, [-1, -1, d], [-1, -1, 3 * d])
+    tol = 2e-5 if dtype == torch.float32 else 2e-3
+    assert_close(grads[d:2 * d], grads_ref[d:2 * d], tol, "dgamma through partial sums")
+    assert_close(grads[3 * d:4 * d], grads_ref[3 * d:4 * d], tol, "dbeta through partial sums")
+    assert torch.equal(grads[:d], before[:d]) and torch.equal(grads[2 * d:3 * d], before[2 * d:3 * d])
