@@ -101,7 +101,7 @@ template <> struct AccOperand<bf16_t> {
 };
 
 // =========================================================================================== forward
-template <typename T, int DH>
+template <typename T, int DH, bool MASK3D>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(A
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int jl = 16 * nt + 4 * g + e, j = kt * 64 + jl;
-        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
+        float v = s[nt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
         if (j >= p.Tk) v = -INFINITY;
         s[nt][e] = v;
         tmax = fmaxf(tmax, v);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
 }
 
 // =========================================================================================== backward: dQ
-template <typename T, int DH>
+template <typename T, int DH, bool MASK3D>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kerne
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int jl = 16 * nt + 4 * g + e, j = kt * 64 + jl;
-        float v = s[nt][e] * p.scale + (mask_ok(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
+        float v = s[nt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
         float pv = (j < p.Tk) ? __expf(v - lse_i) : 0.f;
         float dpv = dp[nt][e];
         if (p.drop_thresh) {
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kerne
 }
 
 // =========================================================================================== backward: dK, dV
-template <typename T, int DH>
+template <typename T, int DH, bool MASK3D>
 __global__ __launch_bounds__(256, (DH == 64 && sizeof(T) == 2) ? 3 : 2) void attn_bwd_dkdv_kernel(AttnP p) {
   constexpr int RB = DH * sizeof(T), NS = RB / 64, NDT = DH / 16;
   typedef typename Frag<T>::type frag_t;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, (DH == 64 && sizeof(T) == 2) ? 3 : 2) void att
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int il = 16 * mt + 4 * g + e, i = qt * 64 + il;
-        float v = s[mt][e] * p.scale + (mask_ok(p, b, i, j, key_ok, qmask_t[il] != 0) ? 0.f : -10000.0f);
+        float v = s[mt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, key_ok, qmask_t[il] != 0) ? 0.f : -10000.0f);
         float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_t[il]) : 0.f;
         float dpv = dp[mt][e], pdv = pv;
         if (p.drop_thresh) {
@@ -767,7 +767,8 @@ template <typename T, int DH> int fwd_launch(const AttnP& p, hipStream_t st) {
   const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
   const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
   ImtProfScope prof(sizeof(T) == 2 ? "attn_fwd_bf16" : "attn_fwd_f32", 4.0 * work, io, st);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), 0, st, p);
+  if (p.mask3d) hipLaunchKernelGGL((attn_fwd_kernel<T, DH, true>), grid, dim3(256), 0, st, p);
+  else          hipLaunchKernelGGL((attn_fwd_kernel<T, DH, false>), grid, dim3(256), 0, st, p);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
@@ -793,12 +794,14 @@ template <typename T, int DH> int bwd_launch(const AttnP& p, hipStream_t st) {
   const double io = ((double)p.B * p.H * DH * sizeof(T)) * (2.0 * p.Tq + 2.0 * p.Tk);
   {
     ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dq_bf16" : "attn_bwd_dq_f32", 6.0 * work, io * 1.5, st);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3(imt_cdiv(p.Tq, 64) * p.H * p.B), dim3(256), 0, st, p);
+    if (p.mask3d) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH, true>), dim3(imt_cdiv(p.Tq, 64) * p.H * p.B), dim3(256), 0, st, p);
+    else          hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH, false>), dim3(imt_cdiv(p.Tq, 64) * p.H * p.B), dim3(256), 0, st, p);
     IMT_CHECK_LAUNCH();
   }
   {
     ImtProfScope prof(sizeof(T) == 2 ? "attn_bwd_dkdv_bf16" : "attn_bwd_dkdv_f32", 8.0 * work, io * 1.5, st);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH>), dim3(imt_cdiv(p.Tk, 64) * p.H * p.B), dim3(256), 0, st, p);
+    if (p.mask3d) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH, true>), dim3(imt_cdiv(p.Tk, 64) * p.H * p.B), dim3(256), 0, st, p);
+    else          hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, DH, false>), dim3(imt_cdiv(p.Tk, 64) * p.H * p.B), dim3(256), 0, st, p);
     IMT_CHECK_LAUNCH();
   }
   return IMT_OK;
