@@ -1219,11 +1219,12 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     if (pipe_ok && splits == 1 && (tiles <= 256 || a->K >= 1024)) variant = 5;
     else variant = (a->layout == IMT_TN) ? 1 : 3;
     // 256 x 256 tiles (profiles/r01_gemm_xl_study.txt): several rounds of short-K tiles (vocabulary projection 797 vs 681
-    // TFLOP/s, batched cross K/V), or one round whose epilogue reads a second matrix (GELU', residual: 500 vs 430)
+    // TFLOP/s, batched cross K/V), or one round whose epilogue touches a second matrix (GELU / GELU' / residual: 500 vs 430)
     const int64_t tiles256 = (int64_t)imt_cdiv(a->M, 256) * imt_cdiv(a->N, 256);
     static const bool no_xl = getenv("IMT_GEMM_NO_XL") != nullptr;
+    static const bool no_xl_gelu = getenv("IMT_GEMM_NO_XL_GELU") != nullptr;  // tuning only
     if (!no_xl && pipe_ok && splits == 1 && a->layout != IMT_TN && !a->a_colsum && a->K < 1024 &&
-        (tiles256 >= 512 || (tiles256 >= 224 && (a->aux_mode == IMT_AUX_DGELU || a->resid))))
+        (tiles256 >= 512 || (tiles256 >= 224 && ((a->aux_mode != IMT_AUX_NONE && !(a->aux_mode == IMT_AUX_GELU_FWD && no_xl_gelu)) || a->resid))))
       variant = 6;
     // a weight gradient with about one 256-tile per CU and a long K (the vocabulary projection's dW: 30000 x 512 x 8128)
     static const bool no_xl_tn = getenv("IMT_GEMM_NO_XL_TN") != nullptr;
