@@ -361,13 +361,13 @@ template <typename T, int NCH>
 int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, void* dx,
                   float* dgamma, float* dbeta, int rows, int d, float yp, uint64_t yseed, void* dx_drop, float dxp,
                   uint64_t dxseed, float* partial, hipStream_t st) {
-  // Every workgroup ends with one fp32 atomic per column (dgamma, dbeta), and that tail is what costs, so the
-  // grid stays at ~256 workgroups; the row phase gets its memory-level parallelism from WPB waves per workgroup
-  // instead (sweeps: profiles/r01_ln_bwd_sweep.txt; 8 waves x 256 workgroups: 17 us at rows=8192, d=512, of which the
-  // row phase alone is 11.5 us).
+  // Without a partial-sum workspace every workgroup ends with one fp32 atomic per column straight into dgamma / dbeta,
+  // and that tail is what costs, so the grid stays at ~256 workgroups and the row phase gets its memory-level
+  // parallelism from WPB waves per workgroup (sweeps: profiles/r01_ln_bwd_sweep.txt).  With the workspace (the stack
+  // backward) the atomics spread over 32 copies and 512 workgroups are faster (C1 step 7.43 -> 7.35 ms).
   int wpb = 8;
   if (const char* e = getenv("IMT_LN_WPB")) wpb = atoi(e);  // tuning hook: 4 | 8 | 16
-  int nblk = 256;
+  int nblk = partial ? 512 : 256;
   if (const char* e = getenv("IMT_LN_BLOCKS")) nblk = atoi(e) > 0 ? atoi(e) : nblk;
   int rpw = imt_cdiv(rows, nblk * wpb);
   if (rpw < 1) rpw = 1;
