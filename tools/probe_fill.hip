@@ -45,7 +45,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* base, size_t spa
     for (int i = 0; i < ppw; ++i) {
       const int p = wave * ppw + i;
       const unsigned soff = step_off + (unsigned)p * piece_stride;  // wave-uniform
-      if (MODE == 0) {
+      if (MODE == 0 || (MODE == 2 && (wave & 1) == 0)) {
         char* dst = smem + (slot * pieces_per_step + p) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)lane_off, (int)soff, 0, 0);
       } else {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* base, size_t spa
 template <int MODE, int SHAPE>
 double run(const char* src, size_t span, int nblocks, int nwaves, int pieces_per_step, int inflight, int pitch, unsigned long long* dout) {
   const int steps = 512;
-  const int lds = MODE == 0 ? inflight * pieces_per_step * 1024 : 0;
+  const int lds = MODE != 1 ? inflight * pieces_per_step * 1024 : 0;
   auto k = fill_kernel<MODE, SHAPE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   double best = 0;
@@ -104,6 +104,10 @@ int main(int argc, char** argv) {
       printf("  registers (2 steps): rows %5.1f contiguous %5.1f\n", c, d);
     }
   }
+  // are the two paths additive?  16 waves, even ones fill LDS by DMA, odd ones load into registers
+  for (int nblocks : {1, 256})
+    printf("mixed, 16 waves (8 DMA + 8 register), %3d workgroups: rows %5.1f contiguous %5.1f GB/s per CU  (8 DMA waves alone: see above)\n", nblocks,
+           run<2, 0>(src, span, nblocks, 16, 32, 3, 1024, dout), run<2, 1>(src, span, nblocks, 16, 32, 3, 1024, dout));
   // the 256-tile kernel's step: 64 KiB, 8 waves, 2 stages
   printf("64-KiB steps, 8 waves, 2 in flight, 256 workgroups: rows %5.1f contiguous %5.1f GB/s per CU\n",
          run<0, 0>(src, span, 256, 8, 64, 2, 1024, dout), run<0, 1>(src, span, 256, 8, 64, 2, 1024, dout));
