@@ -3,7 +3,13 @@
 seq128 b64 MT train step -- on synthetic random-token batches.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or
+     plainly: without WORLD_SIZE in the environment the script starts its own N rank processes, one per GPU, BEFORE
+     anything touches the GPU, and exits with the first non-zero rank exit code.)
+
+The timed loop rotates through 8 distinct synthetic batches and alternates the two language directions, so neither
+cache residency of one batch nor the optimizer's skip of never-touched embedding rows / of the idle language head
+flatters the number.
 
 One "step" = one pass of the hot path over one batch per rank: forward, label-smoothed NLL, backward, RCCL
 gradient all-reduce (N > 1, overlapped), global grad-norm clip, Adam -- the body of ImageMTTrainer.train_epoch
@@ -54,12 +60,16 @@ def algorithmic_flops(c):
     return 3.0 * (enc + dec + out)
 
 
-def make_batch(c, seed, device):
+N_BATCHES = 8  # distinct batches the timed loop rotates through
+
+
+def make_batch(c, seed, device, direction=0):
+    """direction 0: language 0 -> 1, direction 1: language 1 -> 0 (the reference's MT data holds both, README.md:212-216)."""
     g = torch.Generator().manual_seed(seed)
     B, S, T, V = c["B"], c["S"], c["T"], c["V"]
     src = torch.randint(6, V, (B, S), generator=g)
     tgt = torch.randint(6, V, (B, T), generator=g)
-    src[:, 0], tgt[:, 0] = 5, 6          # language tags first (textprocessor.py:29-30), </s> last
+    src[:, 0], tgt[:, 0] = (5, 6) if direction == 0 else (6, 5)   # language tags first (textprocessor.py:29-30), </s> last
     src[:, -1], tgt[:, -1] = 4, 4
     if c.get("ragged"):
         for x, L in ((src, S), (tgt, T)):
@@ -68,7 +78,8 @@ def make_batch(c, seed, device):
                 x[i, lens[i] - 1] = 4
                 x[i, lens[i]:] = 0
     b = {"src_texts": src, "dst_texts": tgt, "src_pad_mask": src != 0, "dst_pad_mask": tgt != 0,
-         "src_langs": torch.zeros(B, dtype=torch.long), "dst_langs": torch.ones(B, dtype=torch.long)}
+         "src_langs": torch.full((B,), direction, dtype=torch.long),
+         "dst_langs": torch.full((B,), 1 - direction, dtype=torch.long)}
     out = {k: v.to(device) if k not in ("src_langs", "dst_langs") else v for k, v in b.items()}
     # the loader's host-side count of non-pad target positions (the reference: train_image_mt.py:253-256); with it the step
     # is enqueued without a device->host read.  IMT_BENCH_NO_COUNT=1: let the step read it back from the device instead.
@@ -90,7 +101,8 @@ def build_model(c, dtype, device):
 
 def cpu_baseline(c, seconds_budget=15.0):
     """Reference-equivalent CPU path (this repo's oracle, kind 'port') timed on the host cores on a bounded sample
-    of the same workload: the C1 model with a batch of 8 of the 64 sentences, full train step."""
+    of the same workload: the C1 model with a batch of B/4 = 16 of the 64 sentences, full train step, on at most 16
+    host threads."""
     from oracle import reference_model as R
     try:
         cores = len(os.sched_getaffinity(0))
@@ -144,6 +156,41 @@ def profile_pass(step_fn, steps=2):
     return sorted(out, key=lambda r: -r["ms"])
 
 
+def self_launch(n):
+    """python bench.py --gpus N without a launcher: start N rank processes of this script (nothing here has touched the
+    GPU yet -- children are started, never exec'd into), wait for all, propagate the first failure."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("[bench] rank %d exited with code %d: stopping the other ranks" % (r, code), file=sys.stderr, flush=True)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,11 +203,13 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     import torch.distributed as dist
     # rehearsal knobs (NOT for measurements): IMT_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
     # IMT_BENCH_BACKEND=gloo carries the collectives, so the N > 1 control flow can be exercised on a one-GPU box
@@ -184,12 +233,19 @@ def main():
     model = build_model(c, dtype, device)
     model.train(not args.no_dropout)  # reference trains with dropout 0.1 (lm_config.py:6,8)
     opt = AdamInverseSqrtWithWarmup(model.parameters(), lr=1e-4, betas=(0.9, 0.98), warmup_updates=4000)
-    batch = make_batch(c, 1234 + rank, device)  # each rank its own batch (weak scaling: global batch = 64 * N)
+    # each rank its own batches (weak scaling: global batch = 64 * N); batch i of every rank has direction i % 2, so all
+    # ranks use the same vocabulary projection in a step and the other one stays out of the gradient exchange
+    batches = [make_batch(c, 1234 + 1000 * i + rank, device, direction=i % 2) for i in range(N_BATCHES)]
+    if os.environ.get("IMT_BENCH_ONE_BATCH") == "1":  # round-1 behaviour, for comparisons only
+        batches = batches[:1]
     sync = GradSync(model) if world > 1 else None
-    ntok_step = int(batch["dst_pad_mask"][:, 1:].sum())
+    ntoks = [int(b["dst_pad_mask"][:, 1:].sum()) for b in batches]
+    counter = [0]
 
     def step():
-        return train_step(model, opt, batch, sync=sync, clip=1.0)
+        i = counter[0] % len(batches)
+        counter[0] += 1
+        return train_step(model, opt, batches[i], sync=sync, clip=1.0, active_head=int(batches[i]["dst_langs"][0]))
 
     def fence():
         if world > 1:
@@ -199,15 +255,22 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    first = counter[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
     fence()
+    ntok_timed = sum(ntoks[(first + k) % len(batches)] for k in range(args.steps))
+    ntok_step = ntok_timed / max(1, args.steps)
     elapsed = time.perf_counter() - t0
+    ntok_all = ntok_timed
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        t = torch.tensor([float(ntok_timed)], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ntok_all = float(t)
     loss_val = float(loss.detach())
 
     # instrumented pass: EVERY rank runs the same extra steps (they contain collectives); only rank 0 records events
@@ -223,7 +286,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = ntok_step * world * args.steps / elapsed
+        value = ntok_all / elapsed   # non-pad target tokens of ALL ranks in the timed steps / max-over-ranks time
         flops = algorithmic_flops(c)
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         # dominant kernel = the kernel kind with the largest summed device time in the instrumented pass
@@ -251,11 +314,17 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": c["desc"], "global_batch": c["B"] * world, "seq_len": c["S"],
-                       "target_tokens_per_step": ntok_step * world, "parallelism": "dp%d" % world,
+                       "target_tokens_per_step": round(ntok_step * world, 1), "parallelism": "dp%d" % world,
+                       "distinct_batches": len(batches), "directions": len({int(b["dst_langs"][0]) for b in batches}),
                        "dropout": 0.0 if args.no_dropout else 0.1, "algorithmic_tflop_per_step": round(flops / 1e12, 3),
                        "final_loss": round(loss_val, 4)},
             "roofline": roofline,
         }
+        adam = [r for r in rows if r["kind"] == "clip_adam"]
+        if adam:  # bytes the optimizer pass is charged per step (34 B per parameter element: nothing is skipped in the count)
+            out["config"]["adam_bytes_per_step"] = round(sum(r["bytes"] for r in adam))
+        if sync is not None:
+            out["config"]["grad_exchange_bytes_per_step"] = sync.exchanged_bytes(0)
         print("[bench] gpu: %.1f tokens/s, %.3f ms/step" % (value, ms_per_step), file=sys.stderr, flush=True)
         if args.breakdown:
             tot = sum(r["ms"] for r in rows)

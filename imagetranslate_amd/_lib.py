@@ -172,8 +172,10 @@ SIGNATURES = {
     "imt_ln_partial_reduce": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "imt_clip_adam": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                               c_int64, c_int, _P]),
+    "imt_clip_scale": (c_int, [_P, c_int64, _P, c_float, c_float, _P]),
     "imt_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
     "imt_gated_mix": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "imt_add_rows_dropout": (c_int, [c_int, _P, c_int, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, _P]),
     "imt_debug_spin": (c_int, [c_int, c_int, c_int, c_int64, _P]),
     "imt_prof_enable": (c_int, [c_int]),
     "imt_prof_report": (c_int, [POINTER(ProfRow), c_int]),

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_kernel(imt_beam_ar
     for (int k = 1; k < BEAM_THREADS / 64; ++k)
       if (better(red_f[k], red_i[k], bs, bi)) { bs = red_f[k]; bi = red_i[k]; }
     ps = bs; pi = bi;
-    if (tid == 0) { cs[t] = bs; ci[t] = bi; }
+    if (tid == 0) { cs[t] = bs; ci[t] = (bi == 0x7fffffff) ? t : bi; }  // (no finite score left, e.g. NaN logits: a valid index)
   }
 }
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_fast_kernel(imt_be
       for (int k = 0; k < K - 1; ++k) { ls[k] = ls[k + 1]; li[k] = li[k + 1]; }
       ls[K - 1] = -INFINITY; li[K - 1] = 0x7fffffff;
     }
-    if (tid == 0) { cs[t] = bs; ci[t] = bi; }
+    if (tid == 0) { cs[t] = bs; ci[t] = (bi == 0x7fffffff) ? t : bi; }  // (no finite score left, e.g. NaN logits: a valid index)
   }
 }
 
@@ -298,8 +298,15 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(imt_beam_args a) {
       if (eligible && better(s, c, bs, bc)) { bs = s; bc = c; }
     }
     wave_best(bs, bc);
+    // NaN scores (bf16 overflow, a damaged checkpoint) are never eligible: fall back to candidate t so that every index
+    // below stays inside its buffer -- the hypothesis is garbage either way, the access must not be
+    if (bc == 0x7fffffff) bc = t;
     ps = bs; pc = bc;
-    if (lane == 0) { top_s[t] = bs; top_f[t] = (long long)(bc / a.beam) * a.V + ci[bc]; }
+    if (lane == 0) {
+      int word = ci[bc];
+      if ((unsigned)word >= (unsigned)a.V) word = 0;
+      top_s[t] = bs; top_f[t] = (long long)(bc / a.beam) * a.V + word;
+    }
   }
   __syncthreads();
   const bool over = a.step > 1 && a.max_lens[b] < (int64_t)a.step + 1;

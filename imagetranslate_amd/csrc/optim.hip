@@ -93,7 +93,43 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
     }
 }
 
+// clip_grad_norm_ alone (in place): the micro-steps of a gradient-accumulation window that do not end in an optimizer
+// step (src/train_image_mt.py:291 clips the accumulated gradient after EVERY backward, :292-295 steps every `accum`)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ sumsq,
+                                                         float max_norm, float grad_scale) {
+  float coef = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    const float total_norm = grad_scale * sqrtf(sumsq[0]);
+    const float c = max_norm / (total_norm + 1e-6f);
+    coef *= (c < 1.f ? c : 1.f);
+  }
+  if (coef == 1.f) return;
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  const int64_t n4 = n & ~(int64_t)3;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += stride) {
+    f32x4 gv = Vec4<float>::load(g + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gv[e] *= coef;
+    Vec4<float>::store(g + i, gv);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 + threadIdx.x; i < n; i += 256) g[i] *= coef;
+}
+
 }  // namespace
+
+extern "C" int imt_clip_scale(float* g, int64_t n, const float* sumsq, float max_norm, float grad_scale, void* stream) {
+  if (n <= 0) return IMT_OK;
+  IMT_CHECK_ARG(g, "clip_scale: null pointer");
+  IMT_CHECK_ARG(((uintptr_t)g & 15) == 0, "clip_scale: 16-B alignment");
+  int blocks = imt_cdiv(n, 4096);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  ImtProfScope prof("clip_scale", 0.0, 8.0 * n, (hipStream_t)stream);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, sumsq, max_norm, grad_scale);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
 
 extern "C" int imt_sumsq(const float* g, int64_t n, float* out, float* partial_ws, void* stream) {
   if (n <= 0) return IMT_OK;

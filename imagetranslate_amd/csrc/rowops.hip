@@ -346,6 +346,28 @@ __global__ __launch_bounds__(256) void gated_mix_kernel(const T* __restrict__ a,
   }
 }
 
+// out[r, :] = dropout(x[r, :] + add[r % period, :])   -- the two dropouts and the "+ location_embedding" of the image head
+// (src/image_model.py:37-41,77-78).  TI -> TO conversion on the way (fp32 region features enter a bf16 model).  The same
+// call with add == nullptr and the forward's seed is the backward of the dropout (element index = r * d + c both times).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void add_rows_dropout_kernel(const TI* __restrict__ x, TO* __restrict__ out,
+                                                               const TO* __restrict__ add, int64_t rows, int d, int period,
+                                                               uint32_t thresh, float inv_keep, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const TO* ar = add ? add + (int64_t)(r % period) * d : nullptr;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = Vec4<TI>::load(x + r * d + c);
+    if (ar) v += Vec4<TO>::load(ar + c);
+    if (thresh) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dropout_keep(seed, (uint64_t)r * d + c + e, thresh) ? v[e] * inv_keep : 0.f;
+    }
+    Vec4<TO>::store(out + r * d + c, v);
+  }
+}
+
 template <typename T, int NCH>
 int ln_fwd_launch(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int rows, int d,
                   float eps, float p, uint64_t seed, hipStream_t st) {
@@ -552,6 +574,29 @@ extern "C" int imt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void
   if (blocks > 2048) blocks = 2048;
   ImtProfScope prof("cast_f32_to_bf16", 0.0, 6.0 * n, (hipStream_t)stream);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+extern "C" int imt_add_rows_dropout(int in_dtype, const void* x, int out_dtype, void* out, const void* add, int64_t rows,
+                                    int d, int period, float dropout_p, uint64_t dropout_seed, void* stream) {
+  IMT_CHECK_ARG((in_dtype == IMT_F32 || in_dtype == IMT_BF16) && (out_dtype == IMT_F32 || out_dtype == IMT_BF16), "add_rows_dropout: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0, "add_rows_dropout: d must be a multiple of 4");
+  IMT_CHECK_ARG(!add || period > 0, "add_rows_dropout: period must be positive");
+  IMT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "add_rows_dropout: dropout_p outside [0, 1)");
+  if (rows <= 0) return IMT_OK;
+  IMT_CHECK_ARG(x && out, "add_rows_dropout: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(imt_cdiv(rows, ROWS_PER_BLOCK));
+  const uint32_t th = dropout_thresh(dropout_p);
+  const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+  ImtProfScope prof("add_rows_dropout", 0.0, (double)rows * d * ((in_dtype == IMT_BF16 ? 2 : 4) + (out_dtype == IMT_BF16 ? 2 : 4)), st);
+#define IMT_ARD(TI, TO) hipLaunchKernelGGL((add_rows_dropout_kernel<TI, TO>), grid, dim3(256), 0, st, (const TI*)x, (TO*)out, (const TO*)add, rows, d, period, th, ik, dropout_seed)
+  if (in_dtype == IMT_F32 && out_dtype == IMT_F32) IMT_ARD(float, float);
+  else if (in_dtype == IMT_F32) IMT_ARD(float, bf16_t);
+  else if (out_dtype == IMT_F32) IMT_ARD(bf16_t, float);
+  else IMT_ARD(bf16_t, bf16_t);
+#undef IMT_ARD
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }

@@ -134,3 +134,115 @@ class MassDataset(Dataset):
 
     def __getitem__(self, item):
         return self.batches[item]
+
+
+# ------------------------------------------------------------------------------------------- image / caption data
+# The CNN trunk is outside the hot path (SURVEY section 8(f) row 4): what the reference computes from pixels with a frozen
+# torchvision ResNet (``ModifiedResnet`` up to ``x8.view().permute()``, src/image_model.py:24-36) enters here as
+# pre-extracted region features.  A feature directory holds ``features.pt`` = torch.save({"paths": [str, ...],
+# "feats": Tensor[n_images, regions, C]}) (read with ``weights_only=True``).  The caption file is the reference's own:
+# marshal of (unique_images: {image id: path}, captions: [(image id, caption ids), ...]) (src/dataset.py:301-306).
+class RegionFeatures:
+    def __init__(self, root_img_dir: str):
+        import os
+        blob = torch.load(os.path.join(root_img_dir, "features.pt"), map_location="cpu", weights_only=True)
+        self.paths = list(blob["paths"])
+        self.feats = blob["feats"]
+        assert self.feats.dim() == 3 and self.feats.size(0) == len(self.paths), "features.pt: feats must be [n_images, regions, C]"
+        self.index = {p: i for i, p in enumerate(self.paths)}
+
+    def get(self, paths) -> torch.Tensor:
+        """[len(paths), regions, C]; an image without features gets zeros (the reference substitutes a black image, :367)."""
+        rows = [self.index.get(p, -1) for p in paths]
+        out = self.feats[[max(r, 0) for r in rows]].clone()
+        for k, r in enumerate(rows):
+            if r < 0:
+                out[k].zero_()
+        return out
+
+
+class ImageCaptionDataset(Dataset):
+    """src/dataset.py:278-376 with region features in place of pixels: captions in file order, a batch closed when it
+    would hold more than ``max_img_per_batch`` images or 2 * L^3 * n > max_capacity * 1e6 (L = longest caption)."""
+
+    def __init__(self, root_img_dir: str, data_bin_file: str, max_capacity: int, text_processor, max_img_per_batch: int,
+                 lex_dict=None, ngpu: int = 1, use_neg_samples: bool = False, features: Optional[RegionFeatures] = None):
+        if lex_dict is not None:
+            raise NotImplementedError("lexical proposals (--dict) are outside the hot path (SURVEY a5)")
+        self.ngpu = ngpu
+        self.pad_idx = text_processor.pad_token_id()
+        self.features = features if features is not None else RegionFeatures(root_img_dir)
+        self.batches, self.image_batches, self.all_captions, self.lang_ids = [], [], [], set()
+        budget = max_capacity * 1000000
+        with open(data_bin_file, "rb") as fp:
+            self.unique_images, captions = marshal.load(fp)
+        tag = text_processor.id2token(captions[0][1][0])
+        self.lang_ids.add(int(captions[0][1][0]))
+        self.lang = text_processor.languages[tag] if tag in text_processor.languages else 0
+        cur, imgs, longest = [], [], 0
+        for image_id, caption in captions:
+            if str(self.unique_images[image_id]).lower().endswith(".png"):
+                continue
+            cap = torch.LongTensor(list(caption))
+            self.all_captions.append(cap)
+            cur.append(cap); imgs.append(image_id)
+            longest = max(longest, cap.numel())
+            over = len(imgs) > max_img_per_batch or 2 * longest ** 3 * len(cur) > budget
+            if over and len(cur) - 1 >= self.ngpu and len(cur) > 1:
+                self._emit(cur[:-1], imgs[:-1])
+                cur, imgs = [cur[-1]], [imgs[-1]]
+                longest = cur[0].numel()
+        if cur:
+            self._emit(cur, imgs)
+
+    def _emit(self, caps, imgs):
+        texts = pad_sequence(caps, batch_first=True, padding_value=self.pad_idx)
+        self.batches.append((texts, texts != self.pad_idx, _first_pad_index(texts, self.pad_idx)))
+        self.image_batches.append(list(imgs))
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, item):
+        texts, mask, pad_indices = self.batches[item]
+        feats = self.features.get([self.unique_images[i] for i in self.image_batches[item]])
+        return {"images": feats, "captions": texts, "pad_idx": pad_indices, "langs": torch.LongTensor([self.lang] * texts.size(0)),
+                "caption_mask": mask, "proposal": None}
+
+
+class ImageCaptionTestDataset(ImageCaptionDataset):
+    """src/dataset.py:396-421: one row per distinct image of the batch, its captions kept as references."""
+
+    def __getitem__(self, item):
+        texts, _, _ = self.batches[item]
+        refs, order = {}, []
+        for row, image_id in enumerate(self.image_batches[item]):
+            if image_id not in refs:
+                refs[image_id] = []
+                order.append(image_id)
+            cap = texts[row]
+            refs[image_id].append(cap)
+        max_len = int(texts.size(1))
+        first_tokens = torch.LongTensor([int(refs[i][0][0]) for i in order])
+        feats = self.features.get([self.unique_images[i] for i in order])
+        return {"images": feats, "img_ids": order, "captions": refs, "first_tokens": first_tokens,
+                "langs": torch.LongTensor([self.lang] * len(order)), "max_len": max_len + 10, "proposal": None}
+
+
+class ImageDataset(Dataset):
+    """src/dataset.py:424-476 (inference): every image of the feature directory, ``max_img_per_batch`` per batch."""
+
+    def __init__(self, root_img_dir: str, max_img_per_batch: int, target_lang: int, first_token: int,
+                 features: Optional[RegionFeatures] = None):
+        self.target_lang, self.first_token = target_lang, first_token
+        self.features = features if features is not None else RegionFeatures(root_img_dir)
+        paths = [p for p in self.features.paths if not p.lower().endswith(".png")]
+        self.image_batches = [paths[i:i + max_img_per_batch] for i in range(0, len(paths), max_img_per_batch)]
+
+    def __len__(self):
+        return len(self.image_batches)
+
+    def __getitem__(self, item):
+        paths = self.image_batches[item]
+        return {"images": self.features.get(paths), "tgt_langs": torch.LongTensor([self.target_lang] * len(paths)),
+                "first_tokens": torch.LongTensor([self.first_token] * len(paths)), "paths": paths}

@@ -305,6 +305,13 @@ def clip_adam(p, g, m, v, p_bf16, sumsq_t, max_norm, grad_scale, lr, beta1, beta
                                    lr, beta1, beta2, eps, step, int(zero_grad), _stream()), "imt_clip_adam")
 
 
+def clip_scale(g, sumsq_t, max_norm, grad_scale=1.0):
+    """g *= grad_scale * min(1, max_norm / (grad_scale * sqrt(sumsq) + 1e-6)), in place (imt_clip_scale)."""
+    _req_cuda(g, sumsq_t)
+    L.check(L.load().imt_clip_scale(_p(g), g.numel(), _p(sumsq_t), max_norm, grad_scale, _stream()), "imt_clip_scale")
+    return g
+
+
 def cast_f32_to_bf16(src, dst):
     _req_cuda(src, dst)
     L.check(L.load().imt_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "imt_cast_f32_to_bf16")
@@ -315,6 +322,20 @@ def gated_mix(a, b, gate):
     _req_cuda(a, b, gate)
     out = torch.empty_like(a)
     L.check(L.load().imt_gated_mix(dt(a), _p(a), _p(b), _p(gate), _p(out), a.shape[0], a.shape[1], _stream()), "imt_gated_mix")
+    return out
+
+
+def add_rows_dropout(x, add=None, out_dtype=None, dropout_p=0.0, dropout_seed=0):
+    """out[r, :] = dropout(x[r, :] + add[r % add.shape[0], :]) for a 2-D x (imt_add_rows_dropout); add may be None."""
+    _req_cuda(x, add)
+    assert x.dim() == 2 and x.is_contiguous()
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    if add is not None:
+        assert add.dtype == out_dtype and add.is_contiguous() and add.shape[1] == x.shape[1]
+    L.check(L.load().imt_add_rows_dropout(dt(x), _p(x), dt(out), _p(out), _p(add), x.shape[0], x.shape[1],
+                                          add.shape[0] if add is not None else 1, float(dropout_p), int(dropout_seed), _stream()),
+            "imt_add_rows_dropout")
     return out
 
 

@@ -9,23 +9,53 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops as O
-from .bert_seq2seq import BertDecoderModel, _LinearFn
+from .bert_seq2seq import BertDecoderModel
 from .mass_seq2seq import MassSeq2Seq
 from .seq2seq import future_mask  # noqa: F401
 
 
-class _AddLocationFn(torch.autograd.Function):
-    """out[b, r, :] = x[b, r, :] + loc[r, :]  (src/image_model.py:40-41) via the embedding kernels."""
+class _ImageHeadFn(torch.autograd.Function):
+    """dropout -> fc (no bias) -> + location_embedding -> dropout (src/image_model.py:35-41,77-78) on the HIP kernels:
+    ``imt_add_rows_dropout`` (input dropout, fp32 features -> compute dtype), ``imt_gemm`` (fc), ``imt_add_rows_dropout``
+    (+ location rows, output dropout).  Backward: the output dropout's mask is regenerated from its seed, the location
+    gradient is a column sum over the batch (``imt_colsum``), the fc gradient one TN GEMM into the flat gradient buffer.
+    The region features are frozen inputs: no gradient flows to them."""
 
     @staticmethod
-    def forward(ctx, x, loc):
-        B, R, d = x.shape
-        ctx.shape = (B, R, d)
-        return x + loc.to(x.dtype).unsqueeze(0)
+    def forward(ctx, anchor, x, head, dtype, p, seed):
+        from .param_store import store_of
+        store = store_of(head).ensure()
+        flat = store.params_for(dtype)
+        w_p, loc_p = head.fc.weight, head.location_embedding.weight
+        d, C = w_p.shape
+        R = loc_p.shape[0]
+        wo, lo = store.offset(w_p), store.offset(loc_p)
+        w = flat[wo:wo + d * C].view(d, C)
+        loc = flat[lo:lo + R * d].view(R, d)
+        B = x.shape[0]
+        if x.shape[1] != R:
+            raise ValueError("image head: %d regions given, location_embedding has %d" % (x.shape[1], R))
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        xd = O.add_rows_dropout(x.reshape(B * R, C).contiguous(), None, out_dtype=dtype, dropout_p=p, dropout_seed=seed)
+        y = O.gemm(xd, w, O.IMT_NT)
+        out = O.add_rows_dropout(y, loc, dropout_p=p, dropout_seed=seed + 1)
+        ctx.store, ctx.wo, ctx.lo, ctx.dims, ctx.p, ctx.seed = store, wo, lo, (B, R, d, C), p, seed
+        ctx.save_for_backward(xd)
+        return out.view(B, R, d)
 
     @staticmethod
-    def backward(ctx, dy):
-        return dy, dy.float().sum(0)
+    def backward(ctx, dout):
+        (xd,) = ctx.saved_tensors
+        store = ctx.store
+        B, R, d, C = ctx.dims
+        dy = O.add_rows_dropout(dout.to(xd.dtype).reshape(B * R, d).contiguous(), None, dropout_p=ctx.p, dropout_seed=ctx.seed + 1)
+        O.colsum(dy.view(B, R * d), store.grad[ctx.lo:ctx.lo + R * d])              # d(location_embedding) += sum over images
+        gw = store.grad[ctx.wo:ctx.wo + d * C].view(d, C)
+        sk = max(1, min((B * R) // 256, 512 // max(1, ((d + 127) // 128) * ((C + 127) // 128))))
+        O.gemm(dy, xd, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk)           # d(fc.weight) += dy^T x
+        store.attach_grad_views()
+        return None, None, None, None, None, None
 
 
 class ImageHead(nn.Module):
@@ -41,15 +71,13 @@ class ImageHead(nn.Module):
 
     def forward(self, grid_hidden, compute_dtype=torch.float32):
         """grid_hidden: region features [B, regions, feat_dim] (the reference's x8.view().permute(), :35-36)."""
+        from .param_store import store_of
         x = grid_hidden.to(self.fc.weight.device)
-        if self.dropout > 0 and self.training:
-            x = torch.nn.functional.dropout(x, p=self.dropout)
-        B, R, C = x.shape
-        y = _LinearFn.apply(x.reshape(B * R, C).to(compute_dtype).contiguous(), self.fc.weight, None, self)
-        out = _AddLocationFn.apply(y.view(B, R, -1), self.location_embedding.weight)
-        if self.dropout > 0 and self.training:
-            out = torch.nn.functional.dropout(out, p=self.dropout)
-        return out, None
+        p = float(self.dropout) if self.training else 0.0
+        fixed = getattr(self, "_imt_dropout_seed", None)
+        seed = (int(fixed) if fixed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())) if p > 0 else 0
+        anchor = store_of(self).ensure().anchor() if torch.is_grad_enabled() else None
+        return _ImageHeadFn.apply(anchor, x, self, compute_dtype, p, seed), None
 
 
 class ImageMassSeq2Seq(MassSeq2Seq):

@@ -7,9 +7,14 @@ tokens, gradients are AVERAGED over ranks, then every rank applies the identical
 
 Design for xGMI: the gradients already live in ONE flat fp32 buffer whose layout is the order in which they become
 final during backward (param_store.py), so a bucket is a contiguous slice -- no flatten/copy kernels.  The stack
-backward is issued layer by layer; after each layer a hook hands the newly final slice to an asynchronous
-all-reduce (RCCL runs it on its own stream, overlapped with the remaining backward kernels).  The 1/world_size is
-folded into the fused clip+Adam kernel (``grad_scale``), so there is no separate scaling pass.
+backward is issued layer by layer; after each layer a hook advances the "final prefix" of the flat buffer, and every
+bucket that lies inside the prefix is handed to an asynchronous all-reduce (RCCL runs it on its own stream, overlapped
+with the remaining backward kernels).  The 1/world_size is folded into the fused clip+Adam kernel (``grad_scale``), so
+there is no separate scaling pass.
+
+The bucket boundaries are STATIC: a fixed list of (start, end) slices derived from the flat layout once per layout
+version.  Ranks may reach their milestones in different orders (``lang_dec=True``: rank A back-propagates through
+decoder[0] while rank B uses decoder[1]), but every rank issues the same sequence of collectives with the same sizes.
 """
 import os
 from typing import List, Optional
@@ -28,9 +33,12 @@ class GradSync:
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._works: List = []
         self._ready = 0       # elements of the flat gradient buffer that are final (prefix)
-        self._launched = 0    # prefix already handed to all-reduce
+        self._next = 0        # index of the next bucket of the schedule to launch
+        self._schedule = []   # [(start, end)] of this step
+        self._schedules = {}  # active head (or None) -> [(start, end)]
         self.store: FlatParams = store_of(model.encoder).ensure()
         self._milestones = self._layer_milestones()
+        self._layout_version = self.store.layout_version
         self.store.segment_hook = self._on_segment
         self.store.output_hook = self.output_layers_done
         if broadcast_params and self.world_size > 1:
@@ -39,6 +47,10 @@ class GradSync:
         self.launched_buckets = []  # (start, end) of the last step, for tests / tuning
 
     # ------------------------------------------------------------------ layout -> readiness milestones
+    def _output_layers(self):
+        m = self.model
+        return list(m.output_layer) if isinstance(m.output_layer, torch.nn.ModuleList) else [m.output_layer]
+
     def _layer_milestones(self):
         """(stack module id, layer index) -> end offset of the flat prefix that is final once that layer's
         backward segment has been issued.  Relies on flat_param_order(): outputs, decoder layers top->bottom (+ its
@@ -69,66 +81,128 @@ class GradSync:
         ms[(id(m.encoder), 0)] = st.total  # embeddings (and anything after them) final at the very end
         return ms
 
+    def bucket_schedule(self, active_head: Optional[int] = None):
+        """The static list of (start, end) all-reduce slices of one step.  ``active_head``: index of the ONE vocabulary
+        projection every rank uses in this step (batches of one language direction on all ranks) -- the other heads have
+        no gradient anywhere and are left out of the exchange, which is what DDP's ``find_unused_parameters=True`` does
+        at src/train_image_mt.py:73 for parameters unused on every rank (61.6 MB of fp32 zeros at C1).  None: exchange
+        everything (always correct)."""
+        sched = self._schedules.get(active_head)
+        if sched is not None:
+            return sched
+        st = self.store
+        ranges = [(0, st.total)]
+        outs = self._output_layers()
+        if active_head is not None and len(outs) > 1:
+            spans = []
+            for o in outs:
+                lo = min(st.offset(o.layer.weight), st.offset(o.layer.bias))
+                hi = max(st.offset(o.layer.weight) + o.layer.weight.numel(), st.offset(o.layer.bias) + o.layer.bias.numel())
+                spans.append((lo, hi))
+            heads_lo, heads_hi = min(s[0] for s in spans), max(s[1] for s in spans)
+            # the heads must be one contiguous run at the front of the buffer with nothing else in between
+            covered = sum(hi - lo for lo, hi in spans)
+            if heads_lo == 0 and covered + 64 * len(spans) >= heads_hi:
+                lo, hi = spans[active_head]
+                ranges = [(lo, hi), (heads_hi, st.total)]
+        sched = []
+        for lo, hi in ranges:
+            s = lo
+            while s < hi:
+                e = min(hi, s + self.bucket_elems)
+                if hi - e < self.bucket_elems // 2:  # no tiny tail bucket
+                    e = hi
+                sched.append((s, e))
+                s = e
+        self._schedules[active_head] = sched
+        return sched
+
+    def exchanged_bytes(self, active_head: Optional[int] = None) -> int:
+        return 4 * sum(e - s for s, e in self.bucket_schedule(active_head))
+
     # ------------------------------------------------------------------ hooks
-    def begin_step(self):
-        self._works, self._ready, self._launched, self.launched_buckets = [], 0, 0, []
+    def begin_step(self, active_head: Optional[int] = None):
+        self._works, self._ready, self._next, self.launched_buckets = [], 0, 0, []
         self.store.ensure()
-        if self.store.layout_version != getattr(self, "_layout_version", None):
+        if self.store.layout_version != self._layout_version:
             self._milestones = self._layer_milestones()
+            self._schedules = {}
             self._layout_version = self.store.layout_version
+        self._schedule = self.bucket_schedule(active_head)
 
     def output_layers_done(self):
         """Call after the loss backward has produced the vocabulary-projection gradients (they sit at the front of the
         flat buffer)."""
-        m, st = self.model, self.store
-        outs = list(m.output_layer) if isinstance(m.output_layer, torch.nn.ModuleList) else [m.output_layer]
-        self._advance(max(st.offset(o.layer.bias) + o.layer.bias.numel() for o in outs))
+        st = self.store
+        self._advance(max(st.offset(o.layer.bias) + o.layer.bias.numel() for o in self._output_layers()))
 
     def _on_segment(self, stack_module, layer_index):
         end = self._milestones.get((id(stack_module), layer_index))
         if end is not None:
             self._advance(end)
 
-    def _advance(self, ready_end: int, flush: bool = False):
+    def _advance(self, ready_end: int):
         if self.world_size <= 1:
             return
         self._ready = max(self._ready, ready_end)
-        while self._ready - self._launched >= self.bucket_elems or (flush and self._ready > self._launched):
-            end = self._ready if (flush or self._ready - self._launched < 2 * self.bucket_elems) else \
-                self._launched + self.bucket_elems
-            view = self.store.grad[self._launched:end]
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.launched_buckets.append((self._launched, end))
-            self._launched = end
+        while self._next < len(self._schedule) and self._schedule[self._next][1] <= self._ready:
+            s, e = self._schedule[self._next]
+            self._works.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.launched_buckets.append((s, e))
+            self._next += 1
 
     def finish(self) -> float:
-        """Flush the tail bucket, wait for every all-reduce; returns the grad_scale (1/world_size) to hand to the
-        fused optimizer step."""
+        """Launch whatever is left of the schedule, wait for every all-reduce; returns the grad_scale (1/world_size) to
+        hand to the fused optimizer step."""
         if self.world_size > 1:
-            self._advance(self.store.total, flush=True)
+            self._advance(self.store.total)
             for w in self._works:
                 w.wait()
             self._works = []
         return 1.0 / self.world_size
 
 
-def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: float = 1.0, epsilon: float = 0.1):
-    """One optimizer step of the MT hot path == body of ImageMTTrainer.train_epoch (src/train_image_mt.py:239-295,
-    accum = 1): forward -> label-smoothed NLL mean -> backward [-> overlapped all-reduce] -> clip -> Adam -> zero."""
-    if sync is not None:
-        sync.begin_step()
+def _loss_of(model, batch, epsilon):
     from .mass_seq2seq import MassSeq2Seq
     if not isinstance(model, MassSeq2Seq):  # plain Seq2Seq takes explicit masks (src/seq2seq.py:146)
-        loss, ntokens = model.loss_fused(batch["src_texts"], batch["dst_texts"], batch["src_pad_mask"],
-                                         batch["dst_pad_mask"], batch["src_langs"], batch["dst_langs"], epsilon=epsilon,
-                                         ntokens=batch.get("ntokens"))
-    else:  # the trainer's model class derives the masks from the ids (src/mass_seq2seq.py:24-25)
-        loss, ntokens = model.loss_fused(src_inputs=batch["src_texts"], tgt_inputs=batch["dst_texts"],
-                                         src_langs=batch["src_langs"], tgt_langs=batch["dst_langs"], epsilon=epsilon)
-    loss.backward()
+        return model.loss_fused(batch["src_texts"], batch["dst_texts"], batch["src_pad_mask"], batch["dst_pad_mask"],
+                                batch["src_langs"], batch["dst_langs"], epsilon=epsilon, ntokens=batch.get("ntokens"))
+    # the trainer's model class derives the masks from the ids (src/mass_seq2seq.py:24-25)
+    return model.loss_fused(src_inputs=batch["src_texts"], tgt_inputs=batch["dst_texts"], src_langs=batch["src_langs"],
+                            tgt_langs=batch["dst_langs"], epsilon=epsilon)
+
+
+def clip_in_place(optimizer, store, max_norm: float, grad_scale: float = 1.0):
+    """``clip_grad_norm_`` on the flat gradient buffer, in place (the micro-steps of an accumulation window that do not
+    end in an optimizer step: src/train_image_mt.py:291 clips after EVERY backward)."""
+    from . import hip_ops as O
+    if optimizer._sumsq is None or optimizer._sumsq.device != store.flat.device:
+        optimizer._sumsq = torch.zeros(1, device=store.flat.device)
+        optimizer._sumsq_ws = torch.empty(1024, device=store.flat.device, dtype=torch.float32)
+    optimizer._sumsq.zero_()
+    O.sumsq(store.grad, optimizer._sumsq, optimizer._sumsq_ws)
+    O.clip_scale(store.grad, optimizer._sumsq, float(max_norm), float(grad_scale))
+
+
+def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: float = 1.0, epsilon: float = 0.1,
+               update: bool = True, active_head: Optional[int] = None, loss_weight: float = 1.0):
+    """One micro-step of the MT hot path == body of ImageMTTrainer.train_epoch (src/train_image_mt.py:239-295):
+    forward -> label-smoothed NLL mean -> backward [-> overlapped all-reduce] -> clip -> (Adam -> zero).
+
+    ``update=False`` is a micro-step inside a gradient-accumulation window (``--acc``): the reference clips the
+    ACCUMULATED gradient after every backward (:291) and steps every ``accum`` micro-steps (:292-295); the data-parallel
+    exchange also happens per micro-step, as under DDP.  ``loss_weight``: ``mtl_weight`` of the captioning trainer
+    (src/train_captioning.py:83).  ``active_head``: see GradSync.bucket_schedule."""
+    if sync is not None:
+        sync.begin_step(active_head)
+    loss, ntokens = _loss_of(model, batch, epsilon)
+    (loss if loss_weight == 1.0 else loss * loss_weight).backward()
     scale = 1.0
     if sync is not None:
         scale = sync.finish()
-    optimizer.step(max_grad_norm=clip, grad_scale=scale, zero_grad=True,
-                   overlap_next_forward=os.environ.get("IMT_ADAM_OVERLAP", "1") != "0")
+    if update:
+        optimizer.step(max_grad_norm=clip, grad_scale=scale, zero_grad=True,
+                       overlap_next_forward=os.environ.get("IMT_ADAM_OVERLAP", "1") != "0")
+    else:
+        clip_in_place(optimizer, store_of(model.encoder).ensure(), clip, scale)
     return loss, ntokens

@@ -148,6 +148,9 @@ class FlatParams:
             from . import hip_ops as O
             if self._shadow is None:
                 self._shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat.device)
+            # the cast reads the WHOLE master buffer and writes the whole shadow: every segment of an optimizer step
+            # still running on its side stream must have landed, not only those above `lo`
+            self.wait_updates(0)
             O.cast_f32_to_bf16(self.flat, self._shadow)
             self._shadow_version = v
             self._shadow_stale = False

@@ -417,6 +417,13 @@ class Seq2Seq(nn.Module):
             st.wait_updates(0)  # an overlapped optimizer step (side stream) must have landed before parameters are read
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        st = self.__dict__.get("_imt_flat_store")
+        if st is not None:
+            st.wait_updates(0)  # copies into parameter views must not race an optimizer step on its side stream
+            st.mark_master_changed()
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
     def save(self, out_dir: str):
         if not os.path.exists(out_dir):
             os.makedirs(out_dir)
@@ -426,8 +433,12 @@ class Seq2Seq(nn.Module):
         torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()},
                    os.path.join(out_dir, "mt_model.state_dict"))
         # build extension (the reference hard-codes 12 heads, src/seq2seq.py:37): remembered beside the reference files
+        extra = {"num_attention_heads": int(self.config.num_attention_heads)}
+        img = self.__dict__.get("_modules", {}).get("image_model")
+        if img is not None and hasattr(img, "fc"):  # channels of the region features the `fc` layer was built for
+            extra["image_feat_dim"] = int(img.fc.in_features)
         with open(os.path.join(out_dir, "imt_config.json"), "w") as fp:
-            json.dump({"num_attention_heads": int(self.config.num_attention_heads)}, fp)
+            json.dump(extra, fp)
 
     @staticmethod
     def load(cls, out_dir: str, tok_dir: str, use_obj: bool = False, text_processor=None, **kw):
@@ -435,13 +446,18 @@ class Seq2Seq(nn.Module):
             from .textprocessor import TextProcessor
             text_processor = TextProcessor(tok_model_path=tok_dir)
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        with open(os.path.join(out_dir, "mt_config"), "rb") as fp:
-            (lang_dec, use_proposals, enc_layer, dec_layer, embed_dim, intermediate_dim, tie_embed, resnet_depth,
-             freeze_image) = pickle.load(fp)
+        from .safe_pickle import load_mt_config  # the reference's pickle file, read without executing anything from it
+        (lang_dec, use_proposals, enc_layer, dec_layer, embed_dim, intermediate_dim, tie_embed, resnet_depth,
+         freeze_image) = load_mt_config(os.path.join(out_dir, "mt_config"))
         extra = os.path.join(out_dir, "imt_config.json")
-        if "num_attention_heads" not in kw and os.path.exists(extra):
+        if os.path.exists(extra):
             with open(extra, "r") as fp:
-                kw["num_attention_heads"] = int(json.load(fp)["num_attention_heads"])
+                saved = json.load(fp)
+            if "num_attention_heads" not in kw and "num_attention_heads" in saved:
+                kw["num_attention_heads"] = int(saved["num_attention_heads"])
+            import inspect
+            if "image_feat_dim" in saved and "image_feat_dim" not in kw and "image_feat_dim" in inspect.signature(cls.__init__).parameters:
+                kw["image_feat_dim"] = int(saved["image_feat_dim"])
         mt_model = cls(text_processor=text_processor, lang_dec=lang_dec, use_proposals=use_proposals, tie_embed=tie_embed,
                        enc_layer=enc_layer, dec_layer=dec_layer, embed_dim=embed_dim, intermediate_dim=intermediate_dim,
                        freeze_image=freeze_image, resnet_depth=resnet_depth, use_obj=use_obj, **kw)

@@ -60,8 +60,8 @@ class TextProcessor:
                 from tokenizers import SentencePieceBPETokenizer
                 self.tokenizer = SentencePieceBPETokenizer(os.path.join(tok_model_path, "vocab.json"),
                                                            os.path.join(tok_model_path, "merges.txt"))
-            with open(os.path.join(tok_model_path, "langs"), "rb") as fp:
-                self.languages = pickle.load(fp)
+            from .safe_pickle import load_langs  # the reference's pickle file, read without executing anything from it
+            self.languages = load_langs(os.path.join(tok_model_path, "langs"))
         self._init_properties(self.languages)
 
     def _init_properties(self, languages):

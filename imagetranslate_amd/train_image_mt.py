@@ -7,19 +7,19 @@ import datetime
 import math
 import os
 import random
-from optparse import OptionParser
-
 import torch
 
 from . import dataset
 from .image_model import ImageMassSeq2Seq
-from .parallel import GradSync, train_step
+from .option_parser import get_img_options_parser
+from .parallel import GradSync, clip_in_place, train_step
 from .textprocessor import TextProcessor
 from .utils import build_optimizer, mass_mask_device
 
 
 class ImageMTTrainer:
-    def __init__(self, model, mask_prob: float = 0.3, clip: float = 1.0, optimizer=None, rank: int = 0, world_size: int = 1):
+    def __init__(self, model, mask_prob: float = 0.3, clip: float = 1.0, optimizer=None, rank: int = 0, world_size: int = 1,
+                 seed: int = 1234, **kwargs):
         self.model = model
         self.clip = clip
         self.optimizer = optimizer
@@ -27,18 +27,35 @@ class ImageMTTrainer:
         self.rank, self.world_size = rank, world_size
         self.sync = GradSync(model) if world_size > 1 else None
         self.best_loss = float("inf")
+        self.seed = seed
+        self.epoch = 0
+        self.micro_step = 0  # backward passes so far: the optimizer steps when this reaches a multiple of `accum`
+        # MASS span / replacement draws: a generator of this rank's own, so that the ranks' batch ORDER (drawn from a
+        # generator every rank seeds identically, below) never depends on how many MASS batches a rank has seen
+        self._mass_rng = random.Random((seed + 1) * 7919 + rank)
+
+    def _finish_micro_step(self, loss, accum: int, scale: float):
+        """clip after EVERY backward, step every `accum` (src/train_image_mt.py:291-295)."""
+        self.micro_step += 1
+        if self.micro_step % max(1, accum) == 0:
+            self.optimizer.step(max_grad_norm=self.clip, grad_scale=scale, zero_grad=True)
+        else:
+            from .param_store import store_of
+            clip_in_place(self.optimizer, store_of(self.model.encoder).ensure(), self.clip, scale)
 
     # one MT batch (src/train_image_mt.py:239-295)
-    def mt_step(self, batch):
+    def mt_step(self, batch, accum: int = 1, loss_weight: float = 1.0):
         batch = {k: (v[0] if isinstance(v, list) else v) for k, v in batch.items()}
-        loss, ntokens = train_step(self.model, self.optimizer, batch, sync=self.sync, clip=self.clip)
+        self.micro_step += 1
+        loss, ntokens = train_step(self.model, self.optimizer, batch, sync=self.sync, clip=self.clip,
+                                   update=(self.micro_step % max(1, accum) == 0), loss_weight=loss_weight)
         return float(loss.detach()), int(ntokens)
 
     # one MASS batch (src/train_image_mt.py:186-236): mask a span, recover it with its original positions
-    def mass_step(self, batch):
+    def mass_step(self, batch, accum: int = 1):
         tp = self.model.text_processor
         src = batch["src_texts"].cuda()  # a device copy: the dataset's tensor is never modified, no unmask needed
-        masked = mass_mask_device(self.mask_prob, batch["pad_idx"], src, tp, seed=random.getrandbits(62))
+        masked = mass_mask_device(self.mask_prob, batch["pad_idx"], src, tp, seed=self._mass_rng.getrandbits(62))
         if self.sync is not None:
             self.sync.begin_step()
         loss, ntokens = self.model.loss_fused(src_inputs=masked["src_text"], tgt_inputs=masked["to_recover"],
@@ -46,7 +63,7 @@ class ImageMTTrainer:
                                               tgt_positions=masked["positions"])
         loss.backward()
         scale = self.sync.finish() if self.sync is not None else 1.0
-        self.optimizer.step(max_grad_norm=self.clip, grad_scale=scale, zero_grad=True)
+        self._finish_micro_step(loss, accum, scale)
         return float(loss.detach()), int(ntokens)
 
     @torch.no_grad()
@@ -61,18 +78,31 @@ class ImageMTTrainer:
         self.model.train()
         return total / max(count, 1)
 
+    def epoch_order(self, n_mt: int, n_mass: int):
+        """This rank's share of the epoch's batches: the same shuffle on every rank (a generator seeded with seed + epoch,
+        nothing else draws from it), padded by wrapping around to a multiple of the world size like torch's
+        DistributedSampler (src/train_image_mt.py:586-589), then strided -- every rank runs the SAME number of steps, so
+        no rank is left waiting in an all-reduce when an epoch ends."""
+        order = [("mt", i) for i in range(n_mt)] + [("mass", i) for i in range(n_mass)]
+        random.Random(self.seed + self.epoch).shuffle(order)
+        if self.world_size > 1 and order:
+            short = (-len(order)) % self.world_size
+            order = order + order[:short]
+        return order[self.rank::self.world_size]
+
     def train_epoch(self, mt_data=None, mass_data=None, dev_data=None, step: int = 0, max_step: int = 10 ** 9,
-                    save_path: str = None, log_every: int = 50, eval_every: int = 500):
-        order = [("mt", i) for i in range(len(mt_data or []))] + [("mass", i) for i in range(len(mass_data or []))]
-        random.shuffle(order)
-        order = order[self.rank::self.world_size]  # DistributedSampler over pre-built batches (:586-589)
+                    save_path: str = None, log_every: int = 50, eval_every: int = 500, accum: int = 1):
+        order = self.epoch_order(len(mt_data or []), len(mass_data or []))
+        self.epoch += 1
         tokens, total_loss, t0 = 0, 0.0, datetime.datetime.now()
         for kind, i in order:
             if step >= max_step:
                 break
             try:
-                loss, n = self.mt_step(mt_data[i]) if kind == "mt" else self.mass_step(mass_data[i])
+                loss, n = self.mt_step(mt_data[i], accum) if kind == "mt" else self.mass_step(mass_data[i], accum)
             except RuntimeError as err:  # the reference trainer skips a failing batch and goes on (:327-333)
+                if self.world_size > 1:
+                    raise  # the other ranks are inside this step's collectives: skipping here would leave them hanging
                 print("skipping batch:", repr(err))
                 self.optimizer.zero_grad()
                 continue
@@ -99,44 +129,34 @@ class ImageMTTrainer:
 
 
 def get_option_parser():
-    parser = OptionParser()
-    parser.add_option("--train", dest="mt_train_path", default=None, help="comma-separated MT example files")
-    parser.add_option("--dev", dest="mt_dev_path", default=None)
-    parser.add_option("--mass_train", dest="mass_train_path", default=None, help="comma-separated monolingual example files")
-    parser.add_option("--tok", dest="tokenizer_path")
-    parser.add_option("--model", dest="model_path", help="directory for the best checkpoint")
-    parser.add_option("--pretrained", dest="pretrained_path", default=None)
-    parser.add_option("--epoch", dest="num_epochs", type="int", default=100)
-    parser.add_option("--step", dest="step", type="int", default=500000)
-    parser.add_option("--batch", dest="batch", type="int", default=6000, help="(S+T)*n budget per batch")
-    parser.add_option("--capacity", dest="total_capacity", type="int", default=600)
-    parser.add_option("--lr", dest="learning_rate", type="float", default=1e-4)
-    parser.add_option("--warmup", dest="warmup", type="int", default=12500)
-    parser.add_option("--clip", dest="clip", type="float", default=1.0)
-    parser.add_option("--mask", dest="mask_prob", type="float", default=0.3)
-    parser.add_option("--embed", dest="embed_dim", type="int", default=768)
-    parser.add_option("--intermediate", dest="intermediate_layer_dim", type="int", default=3072)
-    parser.add_option("--enc", dest="encoder_layer", type="int", default=6)
-    parser.add_option("--dec", dest="decoder_layer", type="int", default=6)
-    parser.add_option("--heads", dest="heads", type="int", default=12)
-    parser.add_option("--max_seq_len", dest="max_seq_len", type="int", default=175)
-    parser.add_option("--tie", action="store_true", dest="tie_embed", default=False)
-    parser.add_option("--ldec", action="store_true", dest="lang_decoder", default=False)
-    parser.add_option("--fp32", action="store_true", dest="fp32", default=False, help="fp32 compute (default bf16)")
-    parser.add_option("--seed", dest="seed", type="int", default=1234)
-    parser.add_option("--eval-steps", dest="eval_steps", type="int", default=500)
-    parser.add_option("--log-steps", dest="log_steps", type="int", default=50)
-    return parser
+    """The reference's flags (src/option_parser.py:37-88: --train_mt, --dev_mt, --mass_train, --acc, --fp16, --beam ...)
+    plus the build's additions (option_parser.py)."""
+    return get_img_options_parser()
 
 
-def train(options):
+def init_distributed():
+    """One process per GPU (src/utils.py:93-97, src/train_image_mt.py:72-76); backend "nccl" is RCCL on ROCm."""
     rank, world = 0, 1
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl")
         rank, world = dist.get_rank(), dist.get_world_size()
+    return rank, world
+
+
+def reject_off_path(options):
+    for flag, val in (("--dict", options.dict_path), ("--langs", options.bt_langs)):
+        if val:
+            raise NotImplementedError("%s: outside the hot path (lexical proposals / back-translation scheduling, DESIGN section 7)" % flag)
+
+
+def train(options):
+    reject_off_path(options)
+    rank, world = init_distributed()
     random.seed(options.seed)
     torch.manual_seed(options.seed)
     tp = TextProcessor(options.tokenizer_path)
@@ -145,15 +165,14 @@ def train(options):
     else:
         model = ImageMassSeq2Seq(text_processor=tp, lang_dec=options.lang_decoder, tie_embed=options.tie_embed,
                                  enc_layer=options.encoder_layer, dec_layer=options.decoder_layer, embed_dim=options.embed_dim,
-                                 intermediate_dim=options.intermediate_layer_dim, num_attention_heads=options.heads)
+                                 intermediate_dim=options.intermediate_layer_dim, num_attention_heads=options.heads,
+                                 resnet_depth=options.resnet_depth, image_feat_dim=options.feat_dim)
     model.set_compute_dtype(torch.float32 if options.fp32 else torch.bfloat16)
     model = model.cuda().train()
-    if world > 1:
-        import torch.distributed as dist
-        from .param_store import store_of
-        dist.broadcast(store_of(model).ensure().flat, src=0)
     optimizer = build_optimizer(model, options.learning_rate, options.warmup)
-    trainer = ImageMTTrainer(model, mask_prob=options.mask_prob, clip=options.clip, optimizer=optimizer, rank=rank, world_size=world)
+    # (GradSync broadcasts rank 0's parameters, like the DDP constructor at src/train_image_mt.py:73)
+    trainer = ImageMTTrainer(model, mask_prob=options.mask_prob, clip=options.clip, optimizer=optimizer, rank=rank, world_size=world,
+                             seed=options.seed)
     pad = tp.pad_token_id()
     mk = lambda cls, path, **kw: cls(max_batch_capacity=options.total_capacity, max_batch=options.batch, pad_idx=pad,
                                      max_seq_len=options.max_seq_len, ngpu=1, **kw, **path)
@@ -164,8 +183,9 @@ def train(options):
     for pth in (options.mass_train_path or "").split(","):
         if pth.strip():
             mass_train += mk(dataset.MassDataset, dict(batch_pickle_dir=pth.strip())).batches
-    if options.mt_dev_path:
-        mt_dev = mk(dataset.MTDataset, dict(batch_pickle_dir=options.mt_dev_path)).batches
+    for pth in (options.mt_dev_path or "").split(","):
+        if pth.strip():
+            mt_dev = (mt_dev or []) + mk(dataset.MTDataset, dict(batch_pickle_dir=pth.strip())).batches
     if rank == 0:
         print("MT batches", len(mt_train), "MASS batches", len(mass_train), "dev batches", len(mt_dev or []), flush=True)
     step = 0
@@ -173,7 +193,8 @@ def train(options):
         if step >= options.step:
             break
         step = trainer.train_epoch(mt_data=mt_train, mass_data=mass_train, dev_data=mt_dev, step=step, max_step=options.step,
-                                   save_path=options.model_path, log_every=options.log_steps, eval_every=options.eval_steps)
+                                   save_path=options.model_path, log_every=options.log_steps, eval_every=options.eval_steps,
+                                   accum=options.accum)
     if mt_dev is not None:
         trainer.validate_and_save(mt_dev, options.model_path)
     elif rank == 0 and options.model_path:

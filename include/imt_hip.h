@@ -229,15 +229,24 @@ int imt_scaled_sum(const float* x, int n, float scale, float* out, void* stream)
  *                   Adam(beta1, beta2, eps, no weight decay, bias-corrected) on fp32 master params ;
  *                   optionally writes the bf16 shadow copy ; optionally zeroes g.
  *                   lr and step are read from the host args (one launch per step).
+ * imt_clip_scale  : g *= grad_scale * min(1, max_norm / (grad_scale * sqrt(sumsq[0]) + 1e-6)) in place: the clip of a
+ *                   gradient-accumulation micro-step that does not end in an optimizer step (train_image_mt.py:291-295:
+ *                   clip after every backward, step every `accum`).
  */
 #define IMT_SUMSQ_WS_FLOATS 1024
 int imt_sumsq(const float* g, int64_t n, float* out, float* partial_ws, void* stream);
 int imt_clip_adam(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* sumsq,
                   float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, int64_t step,
                   int zero_grad, void* stream);
+int imt_clip_scale(float* g, int64_t n, const float* sumsq, float max_norm, float grad_scale, void* stream);
 int imt_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int imt_gated_mix(int dtype, const void* a, const void* b, const void* gate, void* out, int64_t rows, int d,
                   void* stream);
+/* Image head glue (ModifiedResnet head, src/image_model.py:37-41,77-78: dropout -> fc -> + location_embedding -> dropout;
+ * the fc itself is imt_gemm): out[r, :] = dropout(x[r, :] + add[r % period, :]), x of in_dtype, out / add of out_dtype,
+ * add may be NULL (plain dropout; with the forward's seed this is also the dropout's backward). */
+int imt_add_rows_dropout(int in_dtype, const void* x, int out_dtype, void* out, const void* add, int64_t rows, int d,
+                         int period, float dropout_p, uint64_t dropout_seed, void* stream);
 
 
 /* ------------------------------------------------------------------ whole encoder / decoder stacks

@@ -408,23 +408,41 @@ class Seq2Seq(nn.Module):
                 tie(self.output_layer[i], dec.embeddings.word_embeddings)
                 tie(self.encoder.embeddings.token_type_embeddings, dec.embeddings.token_type_embeddings)
         self.use_proposals = use_proposals
-        if self.use_proposals:
-            raise NotImplementedError("lexical proposals (src/seq2seq.py:110-144) are off by default; not in the oracle")
+        if self.use_proposals:  # src/seq2seq.py:79-83
+            self.proposal_embedding = self.encoder.embeddings.word_embeddings
+            self.lexical_gate = nn.Parameter(torch.full((1, self.config.hidden_size), 0.1))
+            self.lexical_layer_norm = nn.LayerNorm(self.config.hidden_size, eps=self.config.layer_norm_eps)
         self.freeze_image = freeze_image
         self.resnet_depth = resnet_depth
 
     def encode(self, src_inputs, src_mask, src_langs, images=None):
         return (self.encoder(src_inputs, attention_mask=src_mask, token_type_ids=src_langs), None)
 
+    def attend_proposal(self, decoder_output, proposals, pad_idx):
+        """src/seq2seq.py:110-144 for a [B, T, d] decoder output and [B, P] proposal ids: every target position attends
+        over the P proposal embeddings (scores = dot products, plain softmax -- the reference's -10000 fill at :132 acts on
+        a copy made by boolean indexing and changes nothing, so pad proposals DO take part), rows whose proposals are all
+        pad get the constant 1e-8 (:139-140), then sigmoid-gated mix with the decoder output (:142-144) and LayerNorm."""
+        emb = self.proposal_embedding(proposals)                                   # [B, P, d]
+        scores = torch.einsum("btd,bpd->btp", decoder_output, emb)                 # :129
+        probs = torch.softmax(scores, dim=-1)                                      # :133
+        values = torch.einsum("btp,bpd->btd", probs, emb)                          # :135
+        all_pad = (proposals == pad_idx).all(dim=-1)                               # :138
+        values = torch.where(all_pad[:, None, None], torch.full_like(values, 1e-8), values)
+        gate = torch.sigmoid(self.lexical_gate + 1e-8)
+        return self.lexical_layer_norm(gate * decoder_output + (1 - gate) * values)
+
     def _decode_and_project(self, encoder_states, enc_mask, tgt_inputs, tgt_mask, tgt_langs_t, batch_lang,
-                            position_ids, log_softmax):
+                            position_ids, log_softmax, proposals=None):
         subseq_mask = future_mask(tgt_mask[:, :-1])
         decoder = self.decoder if not self.lang_dec else self.decoder[batch_lang]
         output_layer = self.output_layer if (not self.lang_dec) and self.tie_embed else self.output_layer[batch_lang]
         dec_out = decoder(encoder_states=encoder_states, input_ids=tgt_inputs[:, :-1],
                           encoder_attention_mask=enc_mask, tgt_attention_mask=subseq_mask,
                           position_ids=position_ids, token_type_ids=tgt_langs_t[:, :-1])
-        flat = dec_out.view(-1, dec_out.size(-1))
+        if self.use_proposals:
+            dec_out = self.attend_proposal(dec_out, proposals, self.text_processor.pad_token_id())
+        flat = dec_out.reshape(-1, dec_out.size(-1))
         sel = flat[tgt_mask[:, 1:].contiguous().view(-1)]
         out = output_layer(sel)
         if log_softmax:
@@ -438,7 +456,7 @@ class Seq2Seq(nn.Module):
         tgt_langs_t = tgt_langs.unsqueeze(-1).expand(-1, tgt_inputs.size(-1))
         encoder_states = self.encode(src_inputs, src_mask, src_langs_t)[0]
         return self._decode_and_project(encoder_states, src_mask, tgt_inputs, tgt_mask, tgt_langs_t, batch_lang,
-                                        None, log_softmax)
+                                        None, log_softmax, proposals=proposals)
 
 
 class MassSeq2Seq(Seq2Seq):

@@ -44,7 +44,7 @@ def test_tokenizer_batches_training_and_translation(cuda, tmp_path, capsys):
                                 "--dst-lang", "xb", "--tok", tok, "--output", os.path.join(d, split + ".batch")])
     model_dir = os.path.join(d, "model")
     opts, _ = train_image_mt.get_option_parser().parse_args(
-        ["--train", os.path.join(d, "train.batch"), "--dev", os.path.join(d, "dev.batch"), "--tok", tok, "--model", model_dir,
+        ["--train_mt", os.path.join(d, "train.batch"), "--dev_mt", os.path.join(d, "dev.batch"), "--tok", tok, "--model", model_dir,
          "--embed", "128", "--intermediate", "512", "--enc", "2", "--dec", "2", "--heads", "4", "--batch", "1500", "--capacity", "50",
          "--lr", "0.002", "--warmup", "40", "--step", "260", "--epoch", "40", "--eval-steps", "130", "--log-steps", "65", "--fp32"])
     trainer = train_image_mt.train(opts)
@@ -97,3 +97,62 @@ def test_trainer_mass_steps_on_device_batches(cuda):
             losses.append(loss)
     k = len(data)
     assert sum(losses[-k:]) / k < 0.75 * sum(losses[:k]) / k, (losses[:k], losses[-k:])
+
+
+def test_captioning_train_and_caption_cli(cuda, tmp_path, capsys):
+    """train_captioning.py / caption.py counterparts end to end on the HIP path: region-feature files in place of pixels,
+    image batches + MT batches as a second task weighted by --mtlw, --acc 2, then beam-search captions from the saved
+    checkpoint.  Image i's caption is a fixed function of its features' class, so the loss must fall."""
+    import marshal
+    from imagetranslate_amd import caption, create_mt_batches, train_captioning, train_tokenizer
+    from imagetranslate_amd.textprocessor import TextProcessor
+    d = str(tmp_path)
+    rnd = random.Random(3)
+    src, dst = _corpus(300, 9)
+    with open(os.path.join(d, "all.txt"), "w") as fw:
+        fw.write("\n".join(["<xa> " + s + " </s>" for s in src] + ["<xb> " + t + " </s>" for t in dst]) + "\n")
+    tok = os.path.join(d, "tok")
+    train_tokenizer.main(["--data", os.path.join(d, "all.txt"), "--vocab_size", "300", "--model", tok])
+    tp = TextProcessor(tok)
+    # 8 image classes; the caption of an image is the class's sentence
+    torch.manual_seed(0)
+    protos = torch.randn(8, 49, 64)
+    class_caps = [src[i] for i in range(8)]
+    n_img = 96
+    labels = [rnd.randrange(8) for _ in range(n_img)]
+    feats = torch.stack([protos[c] + 0.05 * torch.randn(49, 64) for c in labels])
+    paths = ["img%03d.jpg" % i for i in range(n_img)]
+    img_dir = os.path.join(d, "images")
+    os.makedirs(img_dir)
+    torch.save({"paths": paths, "feats": feats}, os.path.join(img_dir, "features.pt"))
+    unique = {i: paths[i] for i in range(n_img)}
+    caps = [(i, tp.tokenize_one_sentence_with_langid(class_caps[labels[i]], tp.token_id("<xa>"))) for i in range(n_img)]
+    caps.sort(key=lambda c: len(c[1]))
+    for name, part in (("train.cap", caps[:80]), ("dev.cap", caps[80:])):
+        with open(os.path.join(d, name), "wb") as fw:
+            marshal.dump((unique, part), fw)
+    with open(os.path.join(d, "mt.xa"), "w") as fw:
+        fw.write("\n".join(src[:200]) + "\n")
+    with open(os.path.join(d, "mt.xb"), "w") as fw:
+        fw.write("\n".join(dst[:200]) + "\n")
+    create_mt_batches.main(["--src", os.path.join(d, "mt.xb"), "--dst", os.path.join(d, "mt.xa"), "--src-lang", "xb", "--dst-lang", "xa",
+                            "--tok", tok, "--output", os.path.join(d, "mt.batch")])
+    model_dir = os.path.join(d, "cap_model")
+    train_captioning.main(["--train", os.path.join(d, "train.cap"), "--dev", os.path.join(d, "dev.cap"), "--image", img_dir,
+                           "--train_mt", os.path.join(d, "mt.batch"), "--tok", tok, "--model", model_dir, "--embed", "128",
+                           "--intermediate", "256", "--enc", "1", "--dec", "2", "--heads", "4", "--feat-dim", "64", "--no-obj",
+                           "--max-image", "16", "--batch", "1200", "--lr", "0.003", "--warmup", "20", "--step", "240", "--epoch", "60",
+                           "--acc", "2", "--mtlw", "0.1", "--log-steps", "40", "--eval-steps", "120", "--fp32"])
+    log = capsys.readouterr().out
+    losses = [float(ln.split("Loss: ")[1].split()[0]) for ln in log.splitlines() if "Epoch Step" in ln]
+    assert len(losses) >= 4 and losses[-1] < 0.7 * losses[0], losses
+    assert os.path.exists(os.path.join(model_dir, "mt_model.state_dict"))
+    out_file = os.path.join(d, "captions.txt")
+    caption.main(["--input", img_dir, "--target", "xa", "--output", out_file, "--tok", tok, "--model", model_dir, "--beam", "2",
+                  "--batch", "32", "--max-len", "24", "--fp32"])
+    lines = open(out_file).read().strip().split("\n")
+    assert len(lines) == n_img and all("\t" in ln for ln in lines)
+    by_path = dict(ln.split("\t", 1) for ln in lines)
+    hit = sum(len(set(by_path[paths[i]].split()) & set(class_caps[labels[i]].split())) / max(1, len(set(class_caps[labels[i]].split())))
+              for i in range(n_img)) / n_img
+    assert hit > 0.3, "captions should reproduce a good share of the class sentences' words (got %.2f)" % hit
