@@ -707,6 +707,10 @@ template <typename T> struct DmaPair {
     kadv = KCONTIG ? 128 : (int)(G::BK * ld * (int64_t)sizeof(T));
     delta = KCONTIG ? (int)(128 * ld * (int64_t)sizeof(T)) : (int)(128 * sizeof(T));
   }
+  // The K advance and the +128-row delta are wave-uniform, but they go into the VECTOR offset: the descriptor's range
+  // check (num_records = valid_bytes, which is what turns the rows past M of a ragged last tile into zeros instead of reads
+  // past the operand) covers vgpr offset + instruction offset only -- the SGPR `soffset` operand is added AFTER the check
+  // (tools/probe_soffset.hip; the round-1 fault of tools/probe_fill.hip was exactly an soffset beyond num_records).
   IMT_DEVICE void issue(char* tiles, int t) const {
     const int wave = __builtin_amdgcn_readfirstlane(wv);
     const int adv = __builtin_amdgcn_readfirstlane(t * kadv), d = __builtin_amdgcn_readfirstlane(delta);
@@ -715,7 +719,7 @@ template <typename T> struct DmaPair {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tiles + h * TILE_BYTES + (4 * i + wave) * 1024),
-                                                 16, voff[i], adv + h * d, 0, 0);
+                                                 16, voff[i] + (adv + h * d), 0, 0, 0);
   }
 };
 

@@ -284,7 +284,7 @@ class Seq2Seq(nn.Module):
         attend_mask = (proposals == pad_idx)
         dt = decoder_output.dtype
         mapped_output = decoder_output.float()
-        proposal_embedding = self.proposal_embedding.weight[proposals].float()
+        proposal_embedding = self.proposal_embedding(proposals).float()  # nn.Embedding with padding_idx: the pad row gets no gradient (:116)
         if decoder_output.dim() == 3:
             proposal_embedding = proposal_embedding.unsqueeze(1).expand(-1, decoder_output.size(1), -1, -1)
             mapped_output = mapped_output.unsqueeze(2)

@@ -12,6 +12,10 @@
                   (parity unpinned) -- this fixture guards the oracle against drift.
 * beam_kat.json : known-answer vectors from the REFERENCE's own src/seq_gen.py get_outputs_until_eos (imported
                   from /root/reference/src): token matrices + eos / size_limit / remove_first_token -> cut rows.
+* config_kat.json: known answers from the REFERENCE's own src/lm_config.py (get_config dicts for three model sizes) and
+                  src/textprocessor.py (the special-token id layout of a tokenizer it trains: pad=0, <s>=1, <unk>=2,
+                  <mask>=3, </s>=4, language tags next; framing of a "<lang> ... </s>" line), both imported from
+                  /root/reference/src.
 * toy_beam.pt   : beam-search token ids from THIS repo's oracle (oracle/seq_gen.py) on the toy model derived from
                   toy_seq2seq.pt by tests/util.py:beam_state_dict (matrices x2, EOS bias) so that hypotheses finish
                   at different steps; text (beam 1 / 4, with and without unpadding) and image-only captioning.
@@ -143,7 +147,44 @@ def make_beam():
         print(k, [len(t) for t in v["tokens"]])
 
 
+def make_config_kat():
+    """Known answers from the REFERENCE's own src/lm_config.py (get_config) and src/textprocessor.py (special-token id layout
+    of a tokenizer it trains itself) -- both import in the build container.  Data only: the config dicts it returns and the
+    ids it assigns."""
+    sys.path.insert(0, "/root/reference/src")
+    import lm_config as ref_cfg
+    import tempfile
+    out = {"source": "rasoolims/ImageTranslate src/lm_config.py get_config, src/textprocessor.py TextProcessor", "configs": []}
+    for args in [dict(vocab_size=30000, pad_token_id=0, bos_token_id=1, eos_token_id=4, enc_layer=6, embed_dim=768, intermediate_dim=3072),
+                 dict(vocab_size=1000, pad_token_id=0, bos_token_id=1, eos_token_id=4, enc_layer=2, embed_dim=128, intermediate_dim=512),
+                 dict(vocab_size=60000, pad_token_id=0, bos_token_id=1, eos_token_id=4, enc_layer=3, embed_dim=512, intermediate_dim=2048)]:
+        out["configs"].append({"args": args, "config": ref_cfg.get_config(**args)})
+    import textprocessor as ref_tp
+    tp = ref_tp.TextProcessor()
+    corpus = os.path.join(ROOT, "tests", "golden", "_tok_corpus.txt")
+    words = ["alpha", "beta", "gamma", "delta", "omega", "sigma", "kappa", "theta"]
+    with open(corpus, "w") as fw:
+        for i in range(400):
+            tag = "<en>" if i % 2 == 0 else "<fa>"
+            fw.write(tag + " " + " ".join(words[(i * 3 + j) % 8] for j in range(3 + i % 5)) + " </s>\n")
+    with tempfile.TemporaryDirectory() as d:
+        try:
+            tp.train_tokenizer(paths=[corpus], vocab_size=120, to_save_dir=d, languages={"<en>": 0, "<fa>": 1})
+        except Exception as e:  # TextProcessor.save fails under tokenizers 0.22 ("Is a directory"); training itself has run
+            out["save_error"] = type(e).__name__
+    ids = {t: tp.tokenizer.token_to_id(t) for t in tp.special_tokens}
+    line = "<en> alpha beta gamma </s>"
+    out["textprocessor"] = {"special_tokens": list(tp.special_tokens), "special_ids": ids,
+                            "pad": tp.pad_token_id(), "bos": tp.bos_token_id(), "unk": tp.unk_token_id(), "mask": tp.mask_token_id(),
+                            "sep": tp.sep_token_id(), "languages": tp.languages, "corpus_seed_words": words,
+                            "framed_line": line, "framed_first_last": [tp.tokenize_one_sentence(line)[0], tp.tokenize_one_sentence(line)[-1]],
+                            "is_lang": {str(i): bool(tp.is_lang(i)) for i in range(8)}}
+    os.remove(corpus)
+    json.dump(out, open(os.path.join(HERE, "config_kat.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    make_config_kat()
     make_loss_kat()
     make_toy()
     make_beam_kat()

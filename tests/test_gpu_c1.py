@@ -126,7 +126,7 @@ def test_c1_fp32_parity_and_dispatch(pair, ragged):
         return loss, ntok
     (loss, ntok), kinds = _kinds_of_step(step)
     assert ntok == n_rows
-    assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref), (float(loss), loss_ref)
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-5 * abs(loss_ref), (float(loss.detach()), loss_ref)
     ours_g = dict(ours.named_parameters())
     for k in GRAD_KEYS:
         assert_close(ours_g[k].grad, g_ref[k], 3e-4, "C1 fp32 grad " + k)
@@ -157,7 +157,7 @@ def test_c1_bf16_parity_and_dispatch(pair, ragged):
         loss.backward()
         return loss, ntok
     (loss, ntok), kinds = _kinds_of_step(step)
-    assert abs(float(loss) - loss_ref) <= 2e-2 * abs(loss_ref), (float(loss), loss_ref)
+    assert abs(float(loss.detach()) - loss_ref) <= 2e-2 * abs(loss_ref), (float(loss.detach()), loss_ref)
     ours_g = dict(ours.named_parameters())
     for k in GRAD_KEYS:
         assert_close(ours_g[k].grad, g_ref[k], 1e-1, "C1 bf16 grad " + k)
@@ -191,7 +191,12 @@ def test_c1_bf16_train_mode_dropout_is_consistent(pair):
             torch.cuda.synchronize()
             grads.append({k: dict(ours.named_parameters())[k].grad.clone() for k in GRAD_KEYS[:4]})
         for k in grads[0]:
-            assert torch.equal(grads[0][k], grads[1][k]), "dropout masks of backward differ from forward's: " + k
+            # bit-equal for the GEMM-produced weight gradients; the embedding / LayerNorm gradients are fp32 atomic sums whose
+            # order varies: 1e-5 (a mask mismatch between forward and backward would be an O(1) difference)
+            if "embeddings" in k or "LayerNorm" in k:
+                assert_close(grads[0][k], grads[1][k], 1e-5, "repeat " + k)
+            else:
+                assert torch.equal(grads[0][k], grads[1][k]), "dropout masks of backward differ from forward's: " + k
         assert torch.isfinite(loss).all()
     finally:
         for st in ours._stacks():

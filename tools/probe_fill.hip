@@ -47,7 +47,10 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* base, size_t spa
       const unsigned soff = step_off + (unsigned)p * piece_stride;  // wave-uniform
       if (MODE == 0 || (MODE == 2 && (wave & 1) == 0)) {
         char* dst = smem + (slot * pieces_per_step + p) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)lane_off, (int)soff, 0, 0);
+        // offsets wrap inside the window and travel in the VECTOR offset: `soffset` is not covered by the descriptor's
+        // range check (tools/probe_soffset.hip), which is how the first version of this probe faulted with a 2-MiB window
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16,
+                                                 (int)((soff + lane_off) & (unsigned)(span_bytes - 1) & ~15u), 0, 0, 0);
       } else {
         u4 v = *reinterpret_cast<const u4*>(base + ((size_t)(soff + lane_off) & (span_bytes - 1) & ~(size_t)15));  // span is 2^k: in bounds
         asm volatile("" : "+v"(v));
@@ -84,9 +87,9 @@ double run(const char* src, size_t span, int nblocks, int nwaves, int pieces_per
 }
 
 int main(int argc, char** argv) {
-  // source window (MiB, a power of two >= 8; default 64 = Infinity-Cache resident, mostly L2 misses)
+  // source window (MiB, a power of two >= 2; default 64 = Infinity-Cache resident, mostly L2 misses)
   size_t mib = argc > 1 ? (size_t)atoi(argv[1]) : 64;
-  if (mib < 8 || (mib & (mib - 1))) { fprintf(stderr, "window must be a power of two >= 8 MiB\n"); return 2; }
+  if (mib < 2 || (mib & (mib - 1))) { fprintf(stderr, "window must be a power of two >= 2 MiB\n"); return 2; }
   const size_t span = mib << 20;
   char* src; (void)hipMalloc(&src, span); (void)hipMemset(src, 1, span);
   unsigned long long* dout; (void)hipMalloc(&dout, 1024 * sizeof(unsigned long long));
