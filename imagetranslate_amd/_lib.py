@@ -152,8 +152,14 @@ SIGNATURES = {
     "imt_last_error": (c_char_p, []),
     "imt_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "imt_gemm_grouped_tn": (c_int, [POINTER(GemmArgs), c_int, _P]),
+    "imt_gemm_bias_residual_ln_supported": (c_int, [c_int, c_int, c_int]),
+    "imt_gemm_bias_residual_ln": (c_int, [c_int, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int,
+                                          c_int, c_float, c_float, c_uint64, _P]),
     "imt_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, _P, _P]),
     "imt_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, _P]),
+    "imt_add_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, _P]),
+    "imt_embed_ln_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                 c_float, c_uint64, _P]),
     "imt_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, c_float,
                                   c_uint64, _P, _P]),
     "imt_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

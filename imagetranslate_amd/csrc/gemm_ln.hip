@@ -1,0 +1,328 @@
+// Dense + bias + dropout + residual + LayerNorm as ONE kernel (HF BertSelfOutput / BertOutput as instantiated by
+// src/bert_seq2seq.py:84-90,139-143:  LayerNorm(dropout(dense(x)) + input_tensor), eps 1e-12).
+//
+// LayerNorm needs whole rows, so the output tile is ROW-COMPLETE: 32 rows x N columns (N = 128, 256, 384 or 512), one
+// workgroup of 8 waves, wave w owns columns [w*N/8, (w+1)*N/8) of all 32 rows (2 x NTW accumulator tiles of 16x16).
+// What this costs and buys on MI355X: a 32-row tile streams the WHOLE weight matrix through every
+// CU (2.1x the LDS-fill bytes per flop of a 128 x 128 tile; every CU reads the same N x K weight, an L2 hit), so the K
+// loop is fill-bound -- but the separate LayerNorm launch, its kernel boundary and the re-read of the pre-LN rows are
+// gone, and 8192 rows still give one workgroup per CU.  imt_stack_forward uses it where that trade wins (K <= N: the
+// attention output projections) and for every row count of incremental decoding, where launches are what costs.
+//
+// K loop: K advances 128 BYTES per tile (64 bf16 / 32 fp32 = two MFMA k-steps; whole cache lines per row segment); a ring
+// slot = A tile [32][128 B] + weight rows [N or N/2][128 B] in the usual XOR-swizzled geometry, filled by LDS-DMA
+// (buffer_load ... lds, 16 B/lane, swizzle on the SOURCE address); 4 slots (3 at N = 384), all but one in flight, one
+// s_barrier per slot, counted vmcnt.
+// Every offset that can pass the end of an operand travels in the VECTOR offset under the descriptor's range check
+// (rows >= M of the last tile read zeros).
+// Epilogue, all in registers: v = acc + bias -> dropout (same element index m*N + n as imt_gemm's epilogue, so
+// imt_layernorm_bwd regenerates the mask) -> + residual (prefetched before the K loop) -> rounded to T (the pre-LN
+// value imt_layernorm_bwd reads) -> two-pass row statistics (lane groups by shuffle, the 8 waves through 2 KiB of LDS)
+// -> y = (x - mean) * rstd * gamma + beta.  C is accumulated as C^T tiles (mfma(Wfrag, Afrag)) like imt_gemm: each
+// lane owns 4 consecutive n of one m, so all global accesses are 8- / 16-byte vectors, a full 128-B line per row and
+// wave over its column tiles.  Without the K-order rotation (IMT_GEMM_LN_NO_ROTATE) the accumulation order over K is the one
+// of every other GEMM variant and the pre-LN values are bit-identical to imt_gemm's.
+#include "mma.hpp"
+
+namespace {
+
+constexpr int LN_BM = 32, LN_THREADS = 512, LN_RB = 128;
+constexpr int LN_A_TILE = LN_BM * LN_RB;  // 4 KiB
+
+struct GemmLnP {
+  const void* A; int64_t lda; int64_t a_bytes;
+  const void* W; int64_t ldw; int64_t w_bytes;
+  const void* bias; const void* resid; int64_t ldr;
+  const void* gamma; const void* beta;
+  void* pre_ln; void* out; int64_t ldo;
+  float* mean; float* rstd;
+  int M, K, rotate, has_bias, has_resid;  // absent bias / residual: the pointers alias gamma (host side) and are loaded anyway
+  float eps, inv_keep; uint32_t drop_thresh; uint64_t seed;
+  unsigned long long* trace;  // tuning only (IMT_TRACE=gemm_ln)
+};
+
+template <int N> IMT_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Ring slot = one K tile (128 B of K per row, two MFMA k-steps) of the A rows [32][128 B] plus 1/SPLIT of the weight rows
+// [N / SPLIT][128 B].  128-B row segments are whole cache lines (a first version with 64-B K steps moved half-used lines:
+// 26 GB/s per CU); at N = 512 a whole K tile would be 68 KiB and only two fit, i.e. ONE tile in flight, so the weight rows of
+// a K tile travel as SPLIT = 2 slots of 36 KiB -- four slots, three in flight.  Slot half h holds, for every wave w, the
+// h-th group of 16*NTS of ITS weight rows (global row w*16*NTW + h*16*NTS + i at slot row w*16*NTS + i), so that over both
+// halves a wave owns 16*NTW CONTIGUOUS columns (full 128-B lines per row in the epilogue's stores).
+// LDS-DMA pieces: 1 KiB = 8 slot rows x 128 B; lane l lands on (row 8*piece + l/8, physical chunk l%8) and fetches logical
+// chunk (l%8) ^ swz(row).  A: 4 pieces (waves 0-3, every slot -- re-sent with the second half: 4 KiB, keeps every slot
+// self-contained and the vmcnt bookkeeping uniform); W: NTS pieces x 2 per wave.
+// (The descriptors live in a struct: a lambda capturing a bare __amdgpu_buffer_rsrc_t makes the host pass drop the kernel's
+// stub without a diagnostic.)
+template <typename T, int NTW, int SPLIT> struct LnDma {
+  static constexpr int NTS = NTW / SPLIT;  // n-tiles (16 columns) per wave and slot
+  static constexpr int WP = 2 * NTS;       // weight pieces per wave and slot (8 slot rows each; a wave owns 16*NTS slot rows)
+  __amdgpu_buffer_rsrc_t ra, rw;
+  int voff_w[WP], voff_a, hstep;
+  IMT_DEVICE void init(const GemmLnP& p, int m0, int wave) {
+    constexpr int ES = sizeof(T);
+    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    const int lane = threadIdx.x & 63, prow = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int lr = wave * 16 * NTS + 8 * i + prow;        // slot row
+      const int n = wave * 16 * NTW + 8 * i + prow;         // global weight row for half 0
+      voff_w[i] = (int)(((int64_t)n * p.ldw) * ES + ((pc ^ swz<LN_RB>(lr)) << 4));
+    }
+    hstep = (int)((int64_t)16 * NTS * p.ldw * ES);          // half h: + h * 16*NTS rows
+    voff_a = 0;
+    if (wave < 4) {
+      const int row = 8 * wave + prow;
+      voff_a = (int)(((int64_t)(m0 + row) * p.lda) * ES + ((pc ^ swz<LN_RB>(row)) << 4));
+    }
+  }
+  // slot memory `st`; K tile kt, weight half h
+  IMT_DEVICE void issue(char* st, int kt, int h, int wave) const {
+    const int adv = kt * LN_RB;
+    if (wave < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + wave * 1024), 16, voff_a + adv, 0, 0, 0);
+    const int wadv = adv + h * hstep;
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + LN_A_TILE + (wave * WP + i) * 1024), 16,
+                                               voff_w[i] + wadv, 0, 0, 0);
+  }
+};
+
+template <typename T, int NTW, int SPLIT, int NST>
+__global__ __launch_bounds__(LN_THREADS) void gemm_ln_kernel(GemmLnP p) {
+  constexpr int N = 128 * NTW, NTS = NTW / SPLIT, WP = 2 * NTS;
+  constexpr int SLOT = LN_A_TILE + (N / SPLIT) * LN_RB;
+  constexpr int ES = sizeof(T);
+  typedef typename Frag<T>::type frag_t;
+  typedef typename Vec4<T>::type raw_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + NST * SLOT);  // [2][8 waves][32 rows]
+
+  const int nblk = (p.M + LN_BM - 1) / LN_BM;
+  const int m0 = imt_xcd_block(blockIdx.x, nblk) * LN_BM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wn = wave * 16 * NTW;
+  const int nt = (int)((int64_t)p.K * ES / LN_RB);  // K tiles
+  const int ns = nt * SPLIT;                        // ring slots to stream
+
+  LnDma<T, NTW, SPLIT> dma;
+  dma.init(p, m0, wave);
+  // K-order rotation: every workgroup streams the SAME weight; workgroup b starts at K tile (b / 8) % nt (b / 8: position among
+  // the workgroups of its XCD), so the workgroups of an XCD read different column blocks of it at any time instead of
+  // all hitting the same lines in lock-step.  Summation order over K differs per workgroup only (deterministic per row block).
+  const int phase = p.rotate ? (int)((blockIdx.x >> 3) % (unsigned)nt) : 0;
+  auto issue = [&](int q) {  // q-th slot of the stream: K tile q / SPLIT (rotated), half q % SPLIT
+    const int k = q / SPLIT + phase;
+    dma.issue(smem + (q % NST) * SLOT, k >= nt ? k - nt : k, q % SPLIT, wave);
+  };
+
+  // ---------------------------------------------------------------- epilogue operands requested up front
+  // NO control flow and no pointer select around these loads: `resid ? resid + .. : gamma` made the compiler branch, reuse
+  // the gamma load's registers on one arm and therefore WAIT for it between the groups -- four serial memory round trips in
+  // front of the first DMA.  An absent bias / residual is passed as an alias of gamma (stride 0) and skipped at its use.
+  const T* bias = reinterpret_cast<const T*>(p.bias);
+  const T* resid = reinterpret_cast<const T*>(p.resid);
+  const T* gamma = reinterpret_cast<const T*>(p.gamma);
+  const T* beta = reinterpret_cast<const T*>(p.beta);
+  raw_t rres[2][NTW], rb[NTW], rg[NTW], rbe[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int n = wn + 16 * j + 4 * g;
+    rb[j] = Vec4<T>::load_raw(bias + n);
+    rg[j] = Vec4<T>::load_raw(gamma + n);
+    rbe[j] = Vec4<T>::load_raw(beta + n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = min(m0 + 16 * i + r, p.M - 1);
+      rres[i][j] = Vec4<T>::load_raw(resid + m * p.ldr + n);
+    }
+  }
+
+  f32x4 acc[2][NTW];  // [m tile][n tile]: n tile h * NTS + j = columns wn + 16 * (h * NTS + j) ..
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---------------------------------------------------------------- K loop over ring slots
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < ns) issue(s0);
+  IMT_STAMP(p.trace, 0);
+  for (int q0 = 0; q0 < ns; q0 += SPLIT) {
+#pragma unroll
+    for (int h = 0; h < SPLIT; ++h) {  // compile-time weight half -> static accumulator indices
+      const int q = q0 + h;
+      const int newer = min(NST - 2, ns - 1 - q);  // slots issued after slot q that may still be in flight
+      if (wave < 4) {
+        if (newer >= 2) wait_vmcnt<2 * (WP + 1)>(); else if (newer == 1) wait_vmcnt<WP + 1>(); else wait_vmcnt<0>();
+      } else {
+        if (newer >= 2) wait_vmcnt<2 * WP>(); else if (newer == 1) wait_vmcnt<WP>(); else wait_vmcnt<0>();
+      }
+      asm volatile("s_barrier" ::: "memory");  // slot q visible to all; the slot read in step q-1 is free for the next DMA
+      if (q == 0) IMT_STAMP(p.trace, 1);
+      if (q + NST - 1 < ns) issue(q + NST - 1);
+      const char* ta = smem + (q % NST) * SLOT;
+      const char* tb = ta + LN_A_TILE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        frag_t fa[2], fb[NTS];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = lds_frag_kcontig<T, LN_RB>(ta, 16 * i, 4 * ks);
+#pragma unroll
+        for (int j = 0; j < NTS; ++j) fb[j] = lds_frag_kcontig<T, LN_RB>(tb, wave * 16 * NTS + 16 * j, 4 * ks);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NTS; ++j) mma16(acc[i][h * NTS + j], fb[j], fa[i]);  // C^T tile: rows <- n, cols <- m
+      }
+    }
+  }
+  IMT_STAMP(p.trace, 2);
+
+  // ---------------------------------------------------------------- epilogue
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m0 + 16 * i + r;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = wn + 16 * j + 4 * g;
+      f32x4 v = acc[i][j];
+      if (p.has_bias) v += Vec4<T>::cvt(rb[j]);
+      if (p.drop_thresh) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = dropout_keep(p.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), p.drop_thresh) ? v[e] * p.inv_keep : 0.f;
+      }
+      if (p.has_resid) v += Vec4<T>::cvt(rres[i][j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = to_f32<T>(from_f32<T>(v[e]));  // the stored pre-LN value is what LayerNorm (and its backward) sees
+        s[i] += v[e];
+      }
+      acc[i][j] = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    s[i] += __shfl_xor(s[i], 16, 64);
+    s[i] += __shfl_xor(s[i], 32, 64);
+    if (g == 0) red[wave * 32 + 16 * i + r] = s[i];
+  }
+  __syncthreads();
+  float mean[2], rstd[2], q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[w * 32 + 16 * i + r];
+    mean[i] = t / (float)N;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mean[i]; q[i] += d * d; }
+    q[i] += __shfl_xor(q[i], 16, 64);
+    q[i] += __shfl_xor(q[i], 32, 64);
+    if (g == 0) red[256 + wave * 32 + 16 * i + r] = q[i];
+  }
+  __syncthreads();
+  IMT_STAMP(p.trace, 3);
+  T* pre = reinterpret_cast<T*>(p.pre_ln);
+  T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[256 + w * 32 + 16 * i + r];
+    rstd[i] = 1.0f / sqrtf(t / (float)N + p.eps);
+    const int64_t m = m0 + 16 * i + r;
+    if (m < p.M) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = wn + 16 * j + 4 * g;
+        const f32x4 gv = Vec4<T>::cvt(rg[j]), bv = Vec4<T>::cvt(rbe[j]);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (acc[i][j][e] - mean[i]) * rstd[i] * gv[e] + bv[e];
+        if (pre) Vec4<T>::store(pre + m * p.ldo + n, acc[i][j]);
+        Vec4<T>::store(out + m * p.ldo + n, y);
+      }
+      if (wave == 0 && g == 0) {
+        if (p.mean) p.mean[m] = mean[i];
+        if (p.rstd) p.rstd[m] = rstd[i];
+      }
+    }
+  }
+  IMT_STAMP(p.trace, 4);
+}
+
+template <typename T, int NTW, int SPLIT, int NST>
+int launch_gemm_ln(const GemmLnP& p, hipStream_t st) {
+  constexpr int N = 128 * NTW;
+  constexpr int LDS = NST * (LN_A_TILE + (N / SPLIT) * LN_RB) + 2 * 8 * 32 * 4;
+  static_assert(LDS <= 160 * 1024, "ring does not fit the CU's LDS");
+  auto k = gemm_ln_kernel<T, NTW, SPLIT, NST>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  const char* kind = sizeof(T) == 2 ? "gemm_ln_bf16" : "gemm_ln_f32";
+  if (imt_prof_enabled() && getenv("IMT_PROF_SHAPES")) kind = imt_prof_intern(kind, p.M, N, p.K);
+  ImtProfScope prof(kind, 2.0 * p.M * N * p.K, ((double)p.M * p.K + (double)N * p.K + 3.0 * p.M * N) * sizeof(T), st);
+  const int blocks = imt_cdiv(p.M, LN_BM);
+  ImtTrace tr("gemm_ln", blocks, st);  // IMT_TRACE=gemm_ln: phases = first slot landed | K loop | row statistics | stores
+  GemmLnP pt = p;
+  pt.trace = tr.dev;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(LN_THREADS), LDS, st, pt);
+  if (tr.dev) fprintf(stderr, "[gemm_ln %s %dx%dx%d]\n", kind, p.M, N, p.K);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
+}  // namespace
+
+extern "C" int imt_gemm_bias_residual_ln_supported(int dtype, int N, int K) {
+  const int es = dtype == IMT_BF16 ? 2 : 4;
+  return (dtype == IMT_F32 || dtype == IMT_BF16) && N >= 128 && N <= 512 && N % 128 == 0 && K > 0 && ((int64_t)K * es) % LN_RB == 0;  // whole 128-byte K tiles
+}
+
+extern "C" int imt_gemm_bias_residual_ln(int dtype, const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                                         const void* resid, int64_t ldr, const void* gamma, const void* beta, void* pre_ln,
+                                         void* out, int64_t ldo, float* mean, float* rstd, int M, int N, int K, float eps,
+                                         float dropout_p, uint64_t dropout_seed, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "gemm_bias_residual_ln: bad dtype");
+  IMT_CHECK_ARG(imt_gemm_bias_residual_ln_supported(dtype, N, K), "gemm_bias_residual_ln: N must be 128, 256, 384 or 512 and K a whole number of 128-byte tiles (N=%d K=%d)", N, K);
+  if (M <= 0) return IMT_OK;
+  const int es = dtype == IMT_BF16 ? 2 : 4, al = 16 / es;
+  IMT_CHECK_ARG(x && w && gamma && beta && out, "gemm_bias_residual_ln: null pointer");
+  IMT_CHECK_ARG(ldx % al == 0 && ldw % al == 0 && ldo % 4 == 0 && (!resid || ldr % 4 == 0), "gemm_bias_residual_ln: leading dimensions must keep rows 16-byte aligned");
+  IMT_CHECK_ARG((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "gemm_bias_residual_ln: x / w must be 16-byte aligned");
+  IMT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "gemm_bias_residual_ln: dropout_p outside [0, 1)");
+  GemmLnP p;
+  p.A = x; p.lda = ldx; p.a_bytes = ((int64_t)(M - 1) * ldx + K) * es;
+  p.W = w; p.ldw = ldw; p.w_bytes = ((int64_t)(N - 1) * ldw + K) * es;
+  IMT_CHECK_ARG(p.a_bytes < (1ll << 31) && p.w_bytes < (1ll << 31), "gemm_bias_residual_ln: operand too large for 32-bit offsets");
+  p.bias = bias ? bias : gamma; p.resid = resid ? resid : gamma; p.ldr = resid ? ldr : 0; p.gamma = gamma; p.beta = beta;
+  p.has_bias = bias != nullptr; p.has_resid = resid != nullptr;
+  p.pre_ln = pre_ln; p.out = out; p.ldo = ldo; p.mean = mean; p.rstd = rstd;
+  p.M = M; p.K = K; p.eps = eps;
+  static const bool no_rotate = getenv("IMT_GEMM_LN_NO_ROTATE") != nullptr;  // tuning / bit-exact cross-checks
+  p.rotate = no_rotate ? 0 : 1;
+  p.drop_thresh = dropout_thresh(dropout_p);
+  p.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  p.seed = dropout_seed;
+  p.trace = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+#define IMT_GLN(T)                                            \
+  switch (N / 128) {                                          \
+    case 1: return launch_gemm_ln<T, 1, 1, 4>(p, st);         \
+    case 2: return launch_gemm_ln<T, 2, 1, 4>(p, st);         \
+    case 3: return launch_gemm_ln<T, 3, 1, 3>(p, st);         \
+    default: return launch_gemm_ln<T, 4, 2, 4>(p, st);        \
+  }
+  if (dtype == IMT_F32) { IMT_GLN(float) }
+  IMT_GLN(bf16_t)
+#undef IMT_GLN
+}

@@ -166,6 +166,26 @@ int linear_bwd_input(const Ctx& c, const void* dy, int64_t lddy, int M, int N, i
   return imt_gemm(&a, c.st);
 }
 
+// y = LayerNorm(dropout(x W^T + b) + resid)  (BertSelfOutput / BertOutput).  One launch of the row-complete fused kernel
+// (gemm_ln.hip) where it wins, else imt_gemm with the residual epilogue + imt_layernorm_fwd.  The fused kernel streams the
+// whole weight through every workgroup (32-row tiles): it pays when K <= N (the attention output projections: the separate
+// LayerNorm launch, its boundary and the re-read of the pre-LN rows cost more than the extra fill) and whenever there are
+// few rows (incremental decoding: launches are what costs there).  IMT_GEMM_LN=0 / 1: never / whenever supported.
+bool fuse_dense_ln(const Ctx& c, int M, int N, int K) {
+  static const int mode = getenv("IMT_GEMM_LN") ? atoi(getenv("IMT_GEMM_LN")) : -1;
+  if (mode == 0 || !imt_gemm_bias_residual_ln_supported(c.dtype, N, K)) return false;
+  if (mode == 1) return true;
+  return K <= N || M <= 1024;
+}
+int dense_resid_ln(const Ctx& c, const void* x, int64_t ldx, int M, int K, int64_t w_off, int64_t b_off, int N, const void* resid,
+                   int64_t g_off, int64_t beta_off, void* pre_ln, void* out, float* mean, float* rstd, float drop_p, uint64_t seed) {
+  if (fuse_dense_ln(c, M, N, K))
+    return imt_gemm_bias_residual_ln(c.dtype, x, ldx, c.P(w_off), K, b_off >= 0 ? c.P(b_off) : nullptr, resid, N, c.P(g_off), c.P(beta_off),
+                                     pre_ln, out, N, mean, rstd, M, N, K, c.m->ln_eps, drop_p, seed, c.st);
+  RC(linear_fwd(c, x, ldx, M, K, w_off, b_off, N, pre_ln, N, resid, N, nullptr, IMT_AUX_NONE, drop_p, seed));
+  return imt_layernorm_fwd(c.dtype, pre_ln, c.P(g_off), c.P(beta_off), out, mean, rstd, M, N, c.m->ln_eps, 0.f, 0, c.st);
+}
+
 // Weight-gradient GEMMs of one layer are collected here and issued as ONE grouped launch at the end of the layer's
 // backward (dW[N,K] += dy[M,N]^T x[M,K] ; db[N] += colsum(dy), fused).
 struct DeferredDW {
@@ -249,8 +269,7 @@ int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void*
     attn_args(c, a, B, T, Tk, w.qkv, d, w.kv, w.kv_ld, offp(w.kv, d, c.es), w.kv_ld, w.ctx, w.lse, ms, ap, site_seed(seed, layer, site0));
   }
   RC(imt_attention_fwd(&a, c.st));
-  RC(linear_fwd(c, w.ctx, d, N, d, p.o_w, p.o_b, d, w.pre_ln, d, x, d, nullptr, IMT_AUX_NONE, hp, site_seed(seed, layer, site0 + 1)));
-  RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.ln_g), c.P(p.ln_b), w.out, w.mean, w.rstd, N, d, c.m->ln_eps, 0.f, 0, c.st));
+  RC(dense_resid_ln(c, w.ctx, d, N, d, p.o_w, p.o_b, d, x, p.ln_g, p.ln_b, w.pre_ln, w.out, w.mean, w.rstd, hp, site_seed(seed, layer, site0 + 1)));
   return IMT_OK;
 }
 
@@ -306,8 +325,7 @@ int ffn_fwd(const Ctx& c, const imt_layer_desc& p, LayerWs& w, const void* x, in
   const int d = c.m->d, ff = c.m->ff;
   const float hp = training ? c.m->hidden_dropout : 0.f;
   RC(linear_fwd(c, x, d, N, d, p.ff1_w, p.ff1_b, ff, w.h, ff, nullptr, 0, w.z, IMT_AUX_GELU_FWD, 0.f, 0));
-  RC(linear_fwd(c, w.h, ff, N, ff, p.ff2_w, p.ff2_b, d, w.pre_ln2, d, x, d, nullptr, IMT_AUX_NONE, hp, site_seed(seed, layer, 8)));
-  RC(imt_layernorm_fwd(c.dtype, w.pre_ln2, c.P(p.ln2_g), c.P(p.ln2_b), w.out, w.mean2, w.rstd2, N, d, c.m->ln_eps, 0.f, 0, c.st));
+  RC(dense_resid_ln(c, w.h, ff, N, ff, p.ff2_w, p.ff2_b, d, x, p.ln2_g, p.ln2_b, w.pre_ln2, w.out, w.mean2, w.rstd2, hp, site_seed(seed, layer, 8)));
   return IMT_OK;
 }
 
@@ -360,11 +378,11 @@ extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io
   const int B = io->B, T = io->T, N = B * T, d = m->d;
   const bool training = io->training != 0;
   const uint64_t seed = io->dropout_seed;
-  RC(imt_embed_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), w.emb_sum, N, T, d,
-                   m->vocab, m->max_pos, m->n_types, c.st));
   void* x0 = (m->n_layers == 0) ? io->out : w.x0;
-  RC(imt_layernorm_fwd(c.dtype, w.emb_sum, c.P(m->emb_ln_g), c.P(m->emb_ln_b), x0, w.emb_mean, w.emb_rstd, N, d, m->ln_eps,
-                       training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), c.st));
+  // BertEmbeddings: gather + sum + LayerNorm + dropout in one launch (the sum is kept for the backward)
+  RC(imt_embed_ln_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), c.P(m->emb_ln_g),
+                      c.P(m->emb_ln_b), w.emb_sum, x0, w.emb_mean, w.emb_rstd, N, T, d, m->vocab, m->max_pos, m->n_types, m->ln_eps,
+                      training ? m->hidden_dropout : 0.f, site_seed(seed, 1000, 0), c.st));
   const void* x = x0;
   const MaskSet self_ms{io->key_mask, io->query_mask, io->mask3d, io->causal};
   const MaskSet cross_ms{io->enc_mask, nullptr, nullptr, 0};
@@ -569,9 +587,8 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
   const int64_t self_layer = (int64_t)io->r_max * row3;
   const int B = R / io->rep;
   const int64_t cross_layer = (int64_t)B * io->Tk * 2 * d;
-  RC(imt_embed_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), w.emb_sum, R, 1, d,
-                   m->vocab, m->max_pos, m->n_types, c.st));
-  RC(imt_layernorm_fwd(c.dtype, w.emb_sum, c.P(m->emb_ln_g), c.P(m->emb_ln_b), w.x, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+  RC(imt_embed_ln_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), c.P(m->emb_ln_g),
+                      c.P(m->emb_ln_b), w.emb_sum, w.x, w.mean, w.rstd, R, 1, d, m->vocab, m->max_pos, m->n_types, m->ln_eps, 0.f, 0, c.st));
   const void* x = w.x;
   for (int l = 0; l < m->n_layers; ++l) {
     const imt_layer_desc& p = m->layers[l];
@@ -587,8 +604,7 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
     a.slots = io->slots; a.ld_slots = io->t_max;
     a.O = w.ctx; a.ldo = d; a.scale = 1.0f / sqrtf((float)dh);
     RC(imt_attention_decode(&a, c.st));
-    RC(linear_fwd(c, w.ctx, d, R, d, p.self_attn.o_w, p.self_attn.o_b, d, w.pre_ln, d, x, d, nullptr, IMT_AUX_NONE, 0.f, 0));
-    RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.self_attn.ln_g), c.P(p.self_attn.ln_b), w.a, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+    RC(dense_resid_ln(c, w.ctx, d, R, d, p.self_attn.o_w, p.self_attn.o_b, d, x, p.self_attn.ln_g, p.self_attn.ln_b, w.pre_ln, w.a, w.mean, w.rstd, 0.f, 0));
     // cross attention against the per-sentence K|V
     RC(linear_fwd(c, w.a, d, R, d, p.cross_attn.qkv_w, p.cross_attn.qkv_b, d, w.q, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
     const void* kv_l = offp(io->cross_kv, l * cross_layer, c.es);
@@ -599,13 +615,11 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
     a.key_mask = io->enc_mask; a.ld_mask = io->Tk;
     a.O = w.ctx; a.ldo = d; a.scale = 1.0f / sqrtf((float)dh);
     RC(imt_attention_decode(&a, c.st));
-    RC(linear_fwd(c, w.ctx, d, R, d, p.cross_attn.o_w, p.cross_attn.o_b, d, w.pre_ln, d, w.a, d, nullptr, IMT_AUX_NONE, 0.f, 0));
-    RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.cross_attn.ln_g), c.P(p.cross_attn.ln_b), w.b, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+    RC(dense_resid_ln(c, w.ctx, d, R, d, p.cross_attn.o_w, p.cross_attn.o_b, d, w.a, p.cross_attn.ln_g, p.cross_attn.ln_b, w.pre_ln, w.b, w.mean, w.rstd, 0.f, 0));
     // feed-forward
     RC(linear_fwd(c, w.b, d, R, d, p.ff1_w, p.ff1_b, ff, w.h, ff, nullptr, 0, w.z, IMT_AUX_GELU_FWD, 0.f, 0));
-    RC(linear_fwd(c, w.h, ff, R, ff, p.ff2_w, p.ff2_b, d, w.pre_ln, d, w.b, d, nullptr, IMT_AUX_NONE, 0.f, 0));
     void* y = (l == m->n_layers - 1) ? io->out : w.x;
-    RC(imt_layernorm_fwd(c.dtype, w.pre_ln, c.P(p.ln2_g), c.P(p.ln2_b), y, w.mean, w.rstd, R, d, m->ln_eps, 0.f, 0, c.st));
+    RC(dense_resid_ln(c, w.h, ff, R, ff, p.ff2_w, p.ff2_b, d, w.b, p.ln2_g, p.ln2_b, w.pre_ln, y, w.mean, w.rstd, 0.f, 0));
     x = y;
   }
   return IMT_OK;

@@ -10,8 +10,18 @@ namespace {
 constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
 
 // ------------------------------------------------------------------------------------------- LayerNorm fwd
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+// Where the rows come from: SRC 0 = x ; 1 = x + resid (the sum is also written: LayerNorm's backward reads it) ;
+// 2 = word[ids] + pos[pos_ids | n % seq_len] + type[type_ids] (HF BertEmbeddings: gather + LayerNorm + dropout in one launch,
+// the sum written for the backward).
+template <typename T> struct LnSrc {
+  const T* x; const T* resid; T* sum_out;
+  const int64_t* ids; const int64_t* pos_ids; const int64_t* type_ids;
+  const T* word; const T* pos; const T* type;
+  int seq_len, vocab, max_pos, n_types;
+};
+
+template <typename T, int NCH, int SRC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnSrc<T> src, const T* __restrict__ gamma,
                                                      const T* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int rows, int d, float eps, uint32_t thresh, float inv_keep,
@@ -19,17 +29,51 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int lane = threadIdx.x & 63;
   const int row = imt_xcd_block(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* xr = x + (int64_t)row * d;
   f32x4 v[NCH], gv[NCH], bv[NCH];
   float s = 0.f;
   // every load of the row is requested up front and unconditionally (columns past d read a clamped address and are
   // masked where used): a load under a branch makes the compiler drain vmcnt at the join, one round trip per load
+  if (SRC == 2) {
+    int64_t wi = src.ids[row];
+    int64_t pi = src.pos_ids ? src.pos_ids[row] : (int64_t)(row % src.seq_len);
+    int64_t ti = src.type_ids ? src.type_ids[row] : 0;
+    // clamp like a defensive gather: out-of-range ids would fault in the reference; here they read row 0
+    if (wi < 0 || wi >= src.vocab) wi = 0;
+    if (pi < 0 || pi >= src.max_pos) pi = 0;
+    if (ti < 0 || ti >= src.n_types) ti = 0;
+    const T* wr = src.word + wi * d;
+    const T* pr = src.pos + pi * d;
+    const T* tr = src.type + ti * d;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = min(lane * 4 + i * 256, d - 4);
-    v[i] = Vec4<T>::load(xr + c);
-    gv[i] = Vec4<T>::load(gamma + c);
-    bv[i] = Vec4<T>::load(beta + c);
+    for (int i = 0; i < NCH; ++i) {
+      const int c = min(lane * 4 + i * 256, d - 4);
+      const f32x4 a = Vec4<T>::load(wr + c), b = Vec4<T>::load(pr + c), t = Vec4<T>::load(tr + c);
+      gv[i] = Vec4<T>::load(gamma + c);
+      bv[i] = Vec4<T>::load(beta + c);
+      v[i] = a + b;
+      v[i] += t;
+    }
+  } else {
+    const T* xr = src.x + (int64_t)row * d;
+    const T* rr = (SRC == 1) ? src.resid + (int64_t)row * d : xr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = min(lane * 4 + i * 256, d - 4);
+      v[i] = Vec4<T>::load(xr + c);
+      if (SRC == 1) v[i] += Vec4<T>::load(rr + c);
+      gv[i] = Vec4<T>::load(gamma + c);
+      bv[i] = Vec4<T>::load(beta + c);
+    }
+  }
+  if (SRC != 0) {  // the stored sum is what the backward (and this LayerNorm) sees: rounded to T
+    T* so = src.sum_out + (int64_t)row * d;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = to_f32<T>(from_f32<T>(v[i][e]));
+      if (c < d) Vec4<T>::store(so + c, v[i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
@@ -369,12 +413,19 @@ __global__ __launch_bounds__(256) void add_rows_dropout_kernel(const TI* __restr
 }
 
 template <typename T, int NCH>
-int ln_fwd_launch(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int rows, int d,
-                  float eps, float p, uint64_t seed, hipStream_t st) {
-  ImtProfScope prof("layernorm_fwd", 0.0, 2.0 * rows * d * sizeof(T), st);
-  hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3(imt_cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, st,
-                     (const T*)x, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd, rows, d, eps, dropout_thresh(p),
-                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+int ln_fwd_launch(int mode, const LnSrc<T>& src, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int rows,
+                  int d, float eps, float p, uint64_t seed, hipStream_t st) {
+  static const char* const kinds[3] = {"layernorm_fwd", "add_layernorm_fwd", "embed_ln_fwd"};
+  ImtProfScope prof(kinds[mode], 0.0, (mode == 0 ? 2.0 : mode == 1 ? 4.0 : 5.0) * rows * d * sizeof(T), st);
+  const dim3 grid(imt_cdiv(rows, ROWS_PER_BLOCK));
+  const uint32_t th = dropout_thresh(p);
+  const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  if (mode == 0)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, 0>), grid, dim3(256), 0, st, src, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd, rows, d, eps, th, ik, seed);
+  else if (mode == 1)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, 1>), grid, dim3(256), 0, st, src, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd, rows, d, eps, th, ik, seed);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NCH, 2>), grid, dim3(256), 0, st, src, (const T*)gamma, (const T*)beta, (T*)y, mean, rstd, rows, d, eps, th, ik, seed);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
@@ -423,6 +474,12 @@ int ln_bwd_launch(const void* dy, const void* x, const void* gamma, const float*
 
 }  // namespace
 
+template <typename T>
+int ln_fwd_dispatch(int mode, const LnSrc<T>& src, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int rows,
+                    int d, float eps, float p, uint64_t seed, hipStream_t st) {
+  IMT_DISPATCH_NCH(ln_fwd_launch, T, d, mode, src, gamma, beta, y, mean, rstd, rows, d, eps, p, seed, st);
+}
+
 extern "C" int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean,
                                  float* rstd, int rows, int d, float eps, float dropout_p, uint64_t dropout_seed,
                                  void* stream) {
@@ -431,8 +488,44 @@ extern "C" int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, co
   if (rows <= 0) return IMT_OK;
   IMT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == IMT_F32) IMT_DISPATCH_NCH(ln_fwd_launch, float, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
-  IMT_DISPATCH_NCH(ln_fwd_launch, bf16_t, d, x, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+  if (dtype == IMT_F32) { LnSrc<float> s{}; s.x = (const float*)x; return ln_fwd_dispatch<float>(0, s, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st); }
+  LnSrc<bf16_t> s{}; s.x = (const bf16_t*)x;
+  return ln_fwd_dispatch<bf16_t>(0, s, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+}
+
+extern "C" int imt_add_layernorm_fwd(int dtype, const void* x, const void* resid, const void* gamma, const void* beta, void* sum_out,
+                                     void* y, float* mean, float* rstd, int rows, int d, float eps, float dropout_p,
+                                     uint64_t dropout_seed, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "add_layernorm_fwd: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0, "add_layernorm_fwd: d must be a positive multiple of 4");
+  if (rows <= 0) return IMT_OK;
+  IMT_CHECK_ARG(x && resid && gamma && beta && sum_out && y && mean && rstd, "add_layernorm_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IMT_F32) {
+    LnSrc<float> s{}; s.x = (const float*)x; s.resid = (const float*)resid; s.sum_out = (float*)sum_out;
+    return ln_fwd_dispatch<float>(1, s, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+  }
+  LnSrc<bf16_t> s{}; s.x = (const bf16_t*)x; s.resid = (const bf16_t*)resid; s.sum_out = (bf16_t*)sum_out;
+  return ln_fwd_dispatch<bf16_t>(1, s, gamma, beta, y, mean, rstd, rows, d, eps, dropout_p, dropout_seed, st);
+}
+
+extern "C" int imt_embed_ln_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids, const void* word,
+                                const void* pos, const void* type, const void* gamma, const void* beta, void* sum_out, void* y,
+                                float* mean, float* rstd, int n_tokens, int seq_len, int d, int vocab, int max_pos, int n_types,
+                                float eps, float dropout_p, uint64_t dropout_seed, void* stream) {
+  IMT_CHECK_ARG(dtype == IMT_F32 || dtype == IMT_BF16, "embed_ln_fwd: bad dtype");
+  IMT_CHECK_ARG(d > 0 && d % 4 == 0 && seq_len > 0, "embed_ln_fwd: bad dims");
+  if (n_tokens <= 0) return IMT_OK;
+  IMT_CHECK_ARG(ids && word && pos && type && gamma && beta && sum_out && y && mean && rstd, "embed_ln_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IMT_F32) {
+    LnSrc<float> s{}; s.ids = ids; s.pos_ids = pos_ids; s.type_ids = type_ids; s.word = (const float*)word; s.pos = (const float*)pos;
+    s.type = (const float*)type; s.sum_out = (float*)sum_out; s.seq_len = seq_len; s.vocab = vocab; s.max_pos = max_pos; s.n_types = n_types;
+    return ln_fwd_dispatch<float>(2, s, gamma, beta, y, mean, rstd, n_tokens, d, eps, dropout_p, dropout_seed, st);
+  }
+  LnSrc<bf16_t> s{}; s.ids = ids; s.pos_ids = pos_ids; s.type_ids = type_ids; s.word = (const bf16_t*)word; s.pos = (const bf16_t*)pos;
+  s.type = (const bf16_t*)type; s.sum_out = (bf16_t*)sum_out; s.seq_len = seq_len; s.vocab = vocab; s.max_pos = max_pos; s.n_types = n_types;
+  return ln_fwd_dispatch<bf16_t>(2, s, gamma, beta, y, mean, rstd, n_tokens, d, eps, dropout_p, dropout_seed, st);
 }
 
 // grads[g_off[i] + c] += sum_k partials[i][k][0][c], grads[b_off[i] + c] += sum_k partials[i][k][1][c]   (k over the copies)

@@ -104,6 +104,24 @@ def gemm_grouped_tn(problems):
     L.check(L.load().imt_gemm_grouped_tn(arr, len(problems), _stream()), "imt_gemm_grouped_tn")
 
 
+def gemm_bias_residual_ln(x, w, bias, resid, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0, want_pre_ln=True):
+    """out = LayerNorm(dropout(x w^T + bias) + resid) in one launch (imt_gemm_bias_residual_ln); returns
+    (out, pre_ln or None, mean, rstd)."""
+    _req_cuda(x, w, bias, resid, gamma, beta)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out = torch.empty((M, N), device=x.device, dtype=x.dtype)
+    pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if want_pre_ln else None
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    L.check(L.load().imt_gemm_bias_residual_ln(dt(x), _p(x), _rowmajor(x), _p(w), _rowmajor(w), _p(bias), _p(resid),
+                                               _rowmajor(resid) if resid is not None else 0, _p(gamma), _p(beta), _p(pre), _p(out), N,
+                                               _p(mean), _p(rstd), M, N, K, eps, dropout_p, dropout_seed, _stream()),
+            "imt_gemm_bias_residual_ln")
+    return out, pre, mean, rstd
+
+
 def colsum(X, out, scale_dev=None):
     _req_cuda(X, out)
     L.check(L.load().imt_colsum(dt(X), _p(X), _rowmajor(X), X.shape[0], X.shape[1], _p(out), _p(scale_dev), _stream()),
@@ -120,6 +138,32 @@ def layernorm_fwd(x, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0):
     L.check(L.load().imt_layernorm_fwd(dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, d, eps,
                                        dropout_p, dropout_seed, _stream()), "imt_layernorm_fwd")
     return y, mean, rstd
+
+
+def add_layernorm_fwd(x, resid, gamma, beta, eps=1e-12, dropout_p=0.0, dropout_seed=0):
+    """(y, x + resid, mean, rstd) with y = dropout(LayerNorm(x + resid)) in one launch (imt_add_layernorm_fwd)."""
+    _req_cuda(x, resid, gamma, beta)
+    rows, d = x.shape
+    y, ssum = torch.empty_like(x), torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    L.check(L.load().imt_add_layernorm_fwd(dt(x), _p(x), _p(resid), _p(gamma), _p(beta), _p(ssum), _p(y), _p(mean), _p(rstd), rows, d,
+                                           eps, dropout_p, dropout_seed, _stream()), "imt_add_layernorm_fwd")
+    return y, ssum, mean, rstd
+
+
+def embed_ln_fwd(ids, pos_ids, type_ids, word, pos, typ, gamma, beta, seq_len, eps=1e-12, dropout_p=0.0, dropout_seed=0):
+    """BertEmbeddings in one launch (imt_embed_ln_fwd): (y, sum, mean, rstd)."""
+    _req_cuda(ids, word, gamma, beta)
+    n, d = ids.numel(), word.shape[1]
+    y = torch.empty((n, d), device=word.device, dtype=word.dtype)
+    ssum = torch.empty_like(y)
+    mean = torch.empty(n, device=word.device, dtype=torch.float32)
+    rstd = torch.empty(n, device=word.device, dtype=torch.float32)
+    L.check(L.load().imt_embed_ln_fwd(dt(word), _p(ids), _p(pos_ids), _p(type_ids), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta),
+                                      _p(ssum), _p(y), _p(mean), _p(rstd), n, seq_len, d, word.shape[0], pos.shape[0], typ.shape[0], eps,
+                                      dropout_p, dropout_seed, _stream()), "imt_embed_ln_fwd")
+    return y, ssum, mean, rstd
 
 
 LN_PARTIAL_COPIES = 32  # IMT_LN_PARTIAL_COPIES (include/imt_hip.h)

@@ -115,6 +115,19 @@ int imt_gemm(const imt_gemm_args* a, void* stream);
  * launch (HOST array of `count` descriptors).  Problems that cannot be grouped fall back to imt_gemm each. */
 int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* stream);
 
+/* Dense + bias + dropout + residual + LayerNorm in ONE launch -- HF BertSelfOutput / BertOutput as instantiated by
+ * src/bert_seq2seq.py:84-90,139-143: out = LayerNorm(dropout(x W^T + bias) + resid; eps), row-complete 32 x N tiles
+ * (imagetranslate_amd/csrc/gemm_ln.hip).  x [M,K] (ldx), w [N,K] (ldw), bias / gamma / beta [N], resid [M,N] (ldr, may be
+ * NULL), all of `dtype`; pre_ln [M,N] (may be NULL) receives the LayerNorm INPUT (what imt_layernorm_bwd reads as x), out
+ * [M,N] its output (both with leading dimension ldo); mean / rstd fp32 [M] (may be NULL).  Dropout uses the element index
+ * m * N + n like imt_gemm's epilogue, so imt_layernorm_bwd(dx_dropout_seed = dropout_seed) regenerates the mask.
+ * Supported: N in {128, 256, 384, 512}, K a whole number of 128-byte tiles (imt_gemm_bias_residual_ln_supported). */
+int imt_gemm_bias_residual_ln_supported(int dtype, int N, int K);
+int imt_gemm_bias_residual_ln(int dtype, const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                              const void* resid, int64_t ldr, const void* gamma, const void* beta, void* pre_ln, void* out,
+                              int64_t ldo, float* mean, float* rstd, int M, int N, int K, float eps, float dropout_p,
+                              uint64_t dropout_seed, void* stream);
+
 /* column sums: out[n] += scale * sum_m X[m,n]  -> bias gradients (fp32, accumulated); scale_dev nullable. */
 int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, const float* scale_dev, void* stream);
 
@@ -127,6 +140,11 @@ int imt_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, 
 int imt_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* mean,
                       float* rstd, int rows, int d, float eps, float dropout_p, uint64_t dropout_seed,
                       void* stream);
+/* y = dropout(LayerNorm(x + resid)), sum_out = x + resid (what imt_layernorm_bwd reads as its x): the residual add of
+ * BertSelfOutput / BertOutput (src/bert_seq2seq.py:84-90) for callers whose dense layer did not fuse it. */
+int imt_add_layernorm_fwd(int dtype, const void* x, const void* resid, const void* gamma, const void* beta, void* sum_out,
+                          void* y, float* mean, float* rstd, int rows, int d, float eps, float dropout_p,
+                          uint64_t dropout_seed, void* stream);
 int imt_layernorm_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int d,
                       float y_dropout_p, uint64_t y_dropout_seed, void* dx_drop, float dx_dropout_p,
@@ -154,6 +172,12 @@ int imt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const i
 int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
                   const void* dsum, float* dword, float* dpos, float* dtype_tab, int n_tokens, int seq_len, int d,
                   int64_t pad_id, void* stream);
+/* BertEmbeddings in ONE launch: sum_out[n,:] = word[ids[n]] + pos[...] + type[...] (kept for the backward),
+ * y = dropout(LayerNorm(sum_out)) -- imt_embed_fwd + imt_layernorm_fwd without the round trip of the sum. */
+int imt_embed_ln_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids, const void* word,
+                     const void* pos, const void* type, const void* gamma, const void* beta, void* sum_out, void* y,
+                     float* mean, float* rstd, int n_tokens, int seq_len, int d, int vocab, int max_pos, int n_types, float eps,
+                     float dropout_p, uint64_t dropout_seed, void* stream);
 
 /* ------------------------------------------------------------------ attention (HF BertSelfAttention)
  * scores = Q K^T * scale + additive mask ; P = softmax ; [dropout(P)] ; O = P V, heads merged in the output.

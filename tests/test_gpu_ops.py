@@ -637,3 +637,90 @@ def test_layernorm_bwd_partial_sums(cuda, dtype):
     assert_close(grads[d:2 * d], grads_ref[d:2 * d], tol, "dgamma through partial sums")
     assert_close(grads[3 * d:4 * d], grads_ref[3 * d:4 * d], tol, "dbeta through partial sums")
     assert torch.equal(grads[:d], before[:d]) and torch.equal(grads[2 * d:3 * d], before[2 * d:3 * d])
+
+
+# ------------------------------------------------------------------------------------------------ fused dense + LayerNorm
+@pytest.mark.parametrize("shape", [(8128, 512, 512), (300, 128, 128), (33, 256, 64), (1000, 384, 2048), (8192, 512, 2048), (5, 512, 128), (70, 512, 64)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_bias_residual_ln_matches_separate_kernels(cuda, dtype, shape):
+    """imt_gemm_bias_residual_ln == imt_gemm(bias, dropout, residual epilogue) followed by imt_layernorm_fwd: the pre-LN
+    matrix equal up to the round-off of a different K-step order (same products, same epilogue arithmetic, same dropout
+    element index -- the dropped positions are identical), LayerNorm output / statistics likewise; and both against torch."""
+    from imagetranslate_amd import hip_ops as O
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    x, xr = _mk((M, K), dtype, cuda, gen=g)
+    w, wr = _mk((N, K), dtype, cuda, scale=1.0 / math.sqrt(K), gen=g)
+    b, br = _mk((N,), dtype, cuda, scale=0.2, gen=g)
+    res, rr = _mk((M, N), dtype, cuda, gen=g)
+    gam, gr = _mk((N,), dtype, cuda, gen=g)
+    bet, ber = _mk((N,), dtype, cuda, scale=0.3, gen=g)
+    for p, with_res, with_bias in ((0.0, True, True), (0.1, True, True), (0.0, False, False)):
+        pre2 = O.gemm(x, w, O.IMT_NT, bias=b if with_bias else None, resid=res if with_res else None, dropout_p=p, dropout_seed=77)
+        out2, mean2, rstd2 = O.layernorm_fwd(pre2, gam, bet, eps=1e-12)
+        out, pre, mean, rstd = O.gemm_bias_residual_ln(x, w, b if with_bias else None, res if with_res else None, gam, bet,
+                                                       eps=1e-12, dropout_p=p, dropout_seed=77)
+        # same products, same epilogue arithmetic, same dropout element index; only the order of the K steps differs per
+        # workgroup (K-order rotation) -- round-off of an fp32 sum / one bf16 rounding step
+        assert_close(pre, pre2.float().cpu(), 1e-5 if dtype == torch.float32 else 8e-3, "pre-LN vs imt_gemm (p=%g)" % p)
+        if p > 0:
+            # the dropped positions (pre-LN == residual exactly) are the same in both paths, up to the rare element whose
+            # product is below half an ulp of the residual in one summation order and not in the other
+            da, db = (pre == res if with_res else pre == 0), (pre2 == res if with_res else pre2 == 0)
+            assert abs(float(da.float().mean()) - p) < 0.01 and float((da != db).float().mean()) < 1e-4, "dropout masks differ"
+        tol = 1e-5 if dtype == torch.float32 else 1.6e-2  # bf16: one rounding step of the output
+        assert_close(out, out2.float().cpu(), tol, "fused LN output vs separate kernels")
+        assert_close(mean, mean2.cpu(), 1e-5, "mean")
+        assert_close(rstd, rstd2.cpu(), 1e-5, "rstd")
+        if p == 0.0:
+            ref_pre = xr @ wr.t() + (br if with_bias else 0) + (rr if with_res else 0)
+            ref = F.layer_norm(ref_pre.to(dtype).float(), (N,), gr, ber, eps=1e-12)
+            assert_close(out, ref, TOL[dtype], "fused LN output vs torch")
+    # no pre-LN output requested (inference): same LayerNorm output
+    out3, pre3, _, _ = O.gemm_bias_residual_ln(x, w, b, res, gam, bet, want_pre_ln=False)
+    assert pre3 is None
+    out4, _, _, _ = O.gemm_bias_residual_ln(x, w, b, res, gam, bet)
+    assert torch.equal(out3, out4)
+
+
+def test_gemm_bias_residual_ln_bad_args(cuda):
+    from imagetranslate_amd import hip_ops as O
+    from imagetranslate_amd._lib import ImtError
+    x = torch.zeros(64, 64, device=cuda)
+    g = torch.ones(640, device=cuda)
+    with pytest.raises(ImtError):  # N = 640 is not supported by the row-complete tile
+        O.gemm_bias_residual_ln(x, torch.zeros(640, 64, device=cuda), None, None, g, g)
+    with pytest.raises(ImtError):  # K = 8 fp32 = 32 bytes: not a whole 128-byte K tile
+        O.gemm_bias_residual_ln(x[:, :8].contiguous(), torch.zeros(128, 8, device=cuda), None, None, g[:128], g[:128])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_ln_and_add_ln_fused_forwards(cuda, dtype):
+    """imt_embed_ln_fwd == imt_embed_fwd + imt_layernorm_fwd and imt_add_layernorm_fwd == (x + resid) + imt_layernorm_fwd,
+    bit for bit (same arithmetic, the sum rounded to T before LayerNorm like the stored sum of the two-launch path)."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(12)
+    V, P, TY, d, B, T = 300, 64, 2, 384, 5, 37
+    word, _ = _mk((V, d), dtype, cuda, gen=g)
+    pos, _ = _mk((P, d), dtype, cuda, gen=g)
+    typ, _ = _mk((TY, d), dtype, cuda, gen=g)
+    gam, gr = _mk((d,), dtype, cuda, gen=g)
+    bet, br = _mk((d,), dtype, cuda, scale=0.2, gen=g)
+    ids = torch.randint(0, V, (B, T), generator=g).to(cuda)
+    tids = torch.randint(0, TY, (B, T), generator=g).to(cuda)
+    pids = torch.randint(0, P, (B, T), generator=g).to(cuda)
+    for pos_ids in (None, pids):
+        for p in (0.0, 0.1):
+            s2 = O.embed_fwd(ids, pos_ids, tids, word, pos, typ, T)
+            y2, m2, r2 = O.layernorm_fwd(s2, gam, bet, dropout_p=p, dropout_seed=9)
+            y, ssum, m, r = O.embed_ln_fwd(ids, pos_ids, tids, word, pos, typ, gam, bet, T, dropout_p=p, dropout_seed=9)
+            assert torch.equal(ssum, s2) and torch.equal(y, y2) and torch.equal(m, m2) and torch.equal(r, r2)
+    ref = F.layer_norm((word.float()[ids] + pos.float()[pids] + typ.float()[tids]).to(dtype).float().cpu().view(-1, d), (d,), gr, br, eps=1e-12)
+    y, _, _, _ = O.embed_ln_fwd(ids, pids, tids, word, pos, typ, gam, bet, T)
+    assert_close(y, ref, TOL[dtype], "embed + LN vs torch")
+    x, _ = _mk((B * T, d), dtype, cuda, gen=g)
+    res, _ = _mk((B * T, d), dtype, cuda, gen=g)
+    y, ssum, m, r = O.add_layernorm_fwd(x, res, gam, bet)
+    s2 = (x.float() + res.float()).to(dtype)
+    y2, m2, r2 = O.layernorm_fwd(s2, gam, bet)
+    assert torch.equal(ssum, s2) and torch.equal(y, y2) and torch.equal(m, m2) and torch.equal(r, r2)
