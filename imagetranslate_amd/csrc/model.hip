@@ -166,16 +166,17 @@ int linear_bwd_input(const Ctx& c, const void* dy, int64_t lddy, int M, int N, i
   return imt_gemm(&a, c.st);
 }
 
-// y = LayerNorm(dropout(x W^T + b) + resid)  (BertSelfOutput / BertOutput).  One launch of the row-complete fused kernel
-// (gemm_ln.hip) where it wins, else imt_gemm with the residual epilogue + imt_layernorm_fwd.  The fused kernel streams the
-// whole weight through every workgroup (32-row tiles): it pays when K <= N (the attention output projections: the separate
-// LayerNorm launch, its boundary and the re-read of the pre-LN rows cost more than the extra fill) and whenever there are
-// few rows (incremental decoding: launches are what costs there).  IMT_GEMM_LN=0 / 1: never / whenever supported.
+// y = LayerNorm(dropout(x W^T + b) + resid)  (BertSelfOutput / BertOutput): imt_gemm with the residual epilogue +
+// imt_layernorm_fwd, or ONE launch of the row-complete fused kernel (gemm_ln.hip).  Measured on MI355X
+// (profiles/r02_gemm_ln_study.txt): the fused kernel streams the whole weight through every workgroup (32-row tiles), which
+// at d = 512 costs what the LayerNorm launch saves (8192 x 512 x 512: 22.2 us against 13.8 + 8.1, C1 step 7.63 against 7.61
+// ms; incremental decoding 0.92 against 0.77 ms per step: its K loop is one serial stream per workgroup) -- it wins only for
+// narrow models (N <= 256: 0.5-0.7x of the pair).  IMT_GEMM_LN=0 / 1: never / whenever supported.
 bool fuse_dense_ln(const Ctx& c, int M, int N, int K) {
   static const int mode = getenv("IMT_GEMM_LN") ? atoi(getenv("IMT_GEMM_LN")) : -1;
   if (mode == 0 || !imt_gemm_bias_residual_ln_supported(c.dtype, N, K)) return false;
   if (mode == 1) return true;
-  return K <= N || M <= 1024;
+  return N <= 256 && K <= 1024;
 }
 int dense_resid_ln(const Ctx& c, const void* x, int64_t ldx, int M, int K, int64_t w_off, int64_t b_off, int N, const void* resid,
                    int64_t g_off, int64_t beta_off, void* pre_ln, void* out, float* mean, float* rstd, float drop_p, uint64_t seed) {

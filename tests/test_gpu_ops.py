@@ -662,16 +662,17 @@ def test_gemm_bias_residual_ln_matches_separate_kernels(cuda, dtype, shape):
                                                        eps=1e-12, dropout_p=p, dropout_seed=77)
         # same products, same epilogue arithmetic, same dropout element index; only the order of the K steps differs per
         # workgroup (K-order rotation) -- round-off of an fp32 sum / one bf16 rounding step
-        assert_close(pre, pre2.float().cpu(), 1e-5 if dtype == torch.float32 else 8e-3, "pre-LN vs imt_gemm (p=%g)" % p)
+        assert_close(pre, pre2.float().cpu(), 1e-5 if dtype == torch.float32 else 1.6e-2, "pre-LN vs imt_gemm (p=%g)" % p)
         if p > 0:
             # the dropped positions (pre-LN == residual exactly) are the same in both paths, up to the rare element whose
             # product is below half an ulp of the residual in one summation order and not in the other
             da, db = (pre == res if with_res else pre == 0), (pre2 == res if with_res else pre2 == 0)
             assert abs(float(da.float().mean()) - p) < 0.01 and float((da != db).float().mean()) < 1e-4, "dropout masks differ"
-        tol = 1e-5 if dtype == torch.float32 else 1.6e-2  # bf16: one rounding step of the output
+        tol = 1e-5 if dtype == torch.float32 else 3.2e-2  # bf16: a rounding step of the pre-LN value and one of the output
         assert_close(out, out2.float().cpu(), tol, "fused LN output vs separate kernels")
-        assert_close(mean, mean2.cpu(), 1e-5, "mean")
-        assert_close(rstd, rstd2.cpu(), 1e-5, "rstd")
+        stol = 1e-5 if dtype == torch.float32 else 2e-3  # bf16: statistics of pre-LN values that differ by rounding steps
+        assert_close(mean, mean2.cpu(), stol, "mean")
+        assert_close(rstd, rstd2.cpu(), stol, "rstd")
         if p == 0.0:
             ref_pre = xr @ wr.t() + (br if with_bias else 0) + (rr if with_res else 0)
             ref = F.layer_norm(ref_pre.to(dtype).float(), (N,), gr, ber, eps=1e-12)
