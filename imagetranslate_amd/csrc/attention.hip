@@ -79,12 +79,10 @@ IMT_DEVICE bool mask_ok(const AttnP& p, int b, int i, int j, bool key_ok, bool q
   }
   return ok;
 }
-// dropout decision for an element index below 2^32: the same bits as dropout_keep(seed, idx) without the 64-bit index
-// arithmetic and one of its five 32-bit multiplies (quarter rate)
-IMT_DEVICE bool dropout_keep32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx, uint32_t thresh) {
-  uint32_t h = mix32(idx ^ seed_lo);
-  h = mix32(h + seed_hi);
-  return h >= thresh;
+// Dropout of the attention probabilities: attn_drop_word / attn_drop_keep (common.hpp) -- one finaliser call per PAIR of
+// neighbouring keys of a query; pair index = ((b*H + h)*Tq + i) * ceil(Tk/2) + (j >> 1).
+IMT_DEVICE uint64_t attn_pair_row(const AttnP& p, int b, int h, int i) {
+  return ((uint64_t)(b * p.H + h) * (uint64_t)p.Tq + (uint64_t)i) * (uint64_t)((p.Tk + 1) >> 1);
 }
 
 // accumulator tiles -> operand fragments of the following product (see mma.hpp, "permuted-K")
@@ -182,15 +180,22 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_fwd_kernel(A
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float pv = __expf(s[nt][e] - m_new);
+        const float pv = __expf(s[nt][e] - m_new);
         psum += pv;
-        if (p.drop_thresh) {
-          const int j = kt * 64 + 16 * nt + 4 * g + e;
-          const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
-          pv = dropout_keep(p.seed, idx, p.drop_thresh) ? pv * p.inv_keep : 0.f;
-        }
         s[nt][e] = pv;
       }
+    if (p.drop_thresh) {
+      const uint32_t key = dropout_key(p.seed);
+      const uint64_t prow = attn_pair_row(p, b, h, i) + (uint64_t)((kt * 64 + 4 * g) >> 1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {  // keys 16nt + 4g + 2e2, +1: one pair
+          const uint32_t w = attn_drop_word(key, prow + 8 * nt + e2);
+          s[nt][2 * e2] = (w & 0xffffu) >= p.drop_thresh ? s[nt][2 * e2] * p.inv_keep : 0.f;
+          s[nt][2 * e2 + 1] = (w >> 16) >= p.drop_thresh ? s[nt][2 * e2 + 1] * p.inv_keep : 0.f;
+        }
+    }
     l_run = l_run * alpha + psum;  // per-lane partial; lanes r, r+16, r+32, r+48 are combined at the end
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
@@ -295,14 +300,17 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_short_kernel(AttnP p) {
       psum += pv;
       s[nt][e] = pv;
     }
-  if (p.drop_thresh) {  // one uniform branch around all 32 elements (host guarantees B*H*Tq*Tk < 2^32 for this kernel)
-    const uint32_t row_idx = ((uint32_t)(b * p.H + h) * (uint32_t)p.Tq + (uint32_t)i) * (uint32_t)p.Tk + 4 * g;
-    const uint32_t slo = (uint32_t)p.seed, shi = (uint32_t)(p.seed >> 32);
+  if (p.drop_thresh) {  // one uniform branch around all 32 elements; 16 finaliser calls for them (pairs of keys)
+    const uint32_t key = dropout_key(p.seed);
+    const uint32_t prow = (uint32_t)attn_pair_row(p, b, h, i) + (uint32_t)(2 * g);  // (host: B*H*Tq*Tk < 2^32 for this kernel)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        s[nt][e] = dropout_keep32(slo, shi, row_idx + 16 * nt + e, p.drop_thresh) ? s[nt][e] * p.inv_keep : 0.f;
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const uint32_t w = attn_drop_word(key, prow + 8 * nt + e2);
+        s[nt][2 * e2] = (w & 0xffffu) >= p.drop_thresh ? s[nt][2 * e2] * p.inv_keep : 0.f;
+        s[nt][2 * e2 + 1] = (w >> 16) >= p.drop_thresh ? s[nt][2 * e2 + 1] * p.inv_keep : 0.f;
+      }
   }
   psum += __shfl_xor(psum, 16, 64);
   psum += __shfl_xor(psum, 32, 64);
@@ -414,10 +422,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 3) void attn_bwd_dq_kerne
         float v = s[nt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, kmask_t[jl] != 0, query_ok) ? 0.f : -10000.0f);
         float pv = (j < p.Tk) ? __expf(v - lse_i) : 0.f;
         float dpv = dp[nt][e];
-        if (p.drop_thresh) {
-          const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
-          dpv = dropout_keep(p.seed, idx, p.drop_thresh) ? dpv * p.inv_keep : 0.f;
-        }
+        if (p.drop_thresh)
+          dpv = attn_drop_keep(attn_drop_word(dropout_key(p.seed), attn_pair_row(p, b, h, i) + (uint64_t)(j >> 1)), j, p.drop_thresh) ? dpv * p.inv_keep : 0.f;
         s[nt][e] = pv * (dpv - delta_i);  // dS^T
       }
 #pragma unroll
@@ -515,8 +521,7 @@ __global__ __launch_bounds__(256, (DH == 64 && sizeof(T) == 2) ? 3 : 2) void att
         float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse_t[il]) : 0.f;
         float dpv = dp[mt][e], pdv = pv;
         if (p.drop_thresh) {
-          const uint64_t idx = (((uint64_t)(b * p.H + h) * p.Tq + i) * p.Tk + j);
-          const bool keep = dropout_keep(p.seed, idx, p.drop_thresh);
+          const bool keep = attn_drop_keep(attn_drop_word(dropout_key(p.seed), attn_pair_row(p, b, h, i) + (uint64_t)(j >> 1)), j, p.drop_thresh);
           dpv = keep ? dpv * p.inv_keep : 0.f;
           pdv = keep ? pv * p.inv_keep : 0.f;
         }
@@ -650,8 +655,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
           mma16(dp[mt], lds_frag_kcontig<T, RB>(dOt, 16 * mt, 4 * ks), vf[ks]);
         }
       }
-      const uint32_t slo = (uint32_t)p.seed, shi = (uint32_t)(p.seed >> 32);
-      const uint32_t col_idx = (uint32_t)(b * p.H + h) * (uint32_t)p.Tq * (uint32_t)p.Tk + (uint32_t)j;  // + i * Tk
+      // pair index of (query i, this lane's key j) = pair_base + i * ceil(Tk / 2): one finaliser call per element here (the
+      // lane's four elements are four different queries)
+      const uint32_t dkey = dropout_key(p.seed);
+      const uint32_t tkp = (uint32_t)((p.Tk + 1) >> 1);
+      const uint32_t pair_base = (uint32_t)(b * p.H + h) * (uint32_t)p.Tq * tkp + (uint32_t)(j >> 1);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         // this lane's 4 consecutive queries: their lse / delta / mask bytes in one LDS read each
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
           float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse4[e]) : 0.f;
           float dpv = dp[mt][e], pdv = pv;
           if (p.drop_thresh) {  // (host guarantees B*H*Tq*Tk < 2^32 for this kernel)
-            const bool keep = dropout_keep32(slo, shi, col_idx + (uint32_t)i * (uint32_t)p.Tk, p.drop_thresh);
+            const bool keep = attn_drop_keep(attn_drop_word(dkey, pair_base + (uint32_t)i * tkp), j, p.drop_thresh);
             dpv = keep ? dpv * p.inv_keep : 0.f;
             pdv = keep ? pv * p.inv_keep : 0.f;
           }

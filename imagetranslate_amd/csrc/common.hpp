@@ -184,20 +184,56 @@ IMT_DEVICE float gelu_erf_grad(float z) {
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG
-// keep(seed, idx): deterministic Bernoulli(1-p) per element index, recomputed identically in backward.
+// Deterministic Bernoulli(1-p) per element, recomputed identically in backward.  One call of the 32-bit finaliser below
+// (lowbias32: two multiplies, three xor-shifts -- a complete avalanche by itself) yields 32 good bits = TWO 16-bit
+// draws; the decision of element idx of a row-major tensor is draw (idx & 3) of the block (idx >> 2): two finaliser
+// calls per FOUR consecutive elements, which is what every lane of the GEMM / LayerNorm / embedding kernels holds
+// (round 1 spent two calls -- four quarter-rate multiplies -- per element; the attention and epilogue element phases
+// are VALU-bound).  p is realised as round(p * 65536) / 65536 (0.1 -> 0.100006).
 IMT_DEVICE uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-IMT_DEVICE bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh /* p * 2^32 */) {
-  // two rounds of a 32-bit finaliser over (index, seed): ~12 integer ops per element
-  uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
-  h = mix32(h + (uint32_t)(idx >> 32) * 0x9e3779b9U + (uint32_t)(seed >> 32));
-  return h >= thresh;
+IMT_DEVICE uint32_t dropout_key(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9U); }
+// the 4 x 16 draws of block idx4 (= element index >> 2) as two words
+IMT_DEVICE void dropout_block(uint32_t key, uint64_t idx4, uint32_t& h_lo, uint32_t& h_hi) {
+  h_lo = mix32(((uint32_t)idx4 ^ key) + (uint32_t)(idx4 >> 32) * 0x85ebca6bU);
+  h_hi = mix32(h_lo + 0x9e3779b9U);
 }
+IMT_DEVICE bool dropout_draw(uint32_t h_lo, uint32_t h_hi, int e /* 0..3 */, uint32_t thresh16) {
+  const uint32_t w = (e & 2) ? h_hi : h_lo;
+  return ((e & 1) ? (w >> 16) : (w & 0xffffu)) >= thresh16;
+}
+// single element (edge tiles, tails); same decision as the block form
+IMT_DEVICE bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh16) {
+  uint32_t lo, hi;
+  dropout_block(dropout_key(seed), idx >> 2, lo, hi);
+  return dropout_draw(lo, hi, (int)(idx & 3), thresh16);
+}
+// v[e] <- keep(idx0 + e) ? v[e] * inv_keep : 0 for the 4 consecutive elements idx0 .. idx0 + 3, idx0 % 4 == 0
+IMT_DEVICE void dropout_apply4(f32x4& v, uint64_t seed, uint64_t idx0, uint32_t thresh16, float inv_keep) {
+  uint32_t lo, hi;
+  dropout_block(dropout_key(seed), idx0 >> 2, lo, hi);
+  v[0] = (lo & 0xffffu) >= thresh16 ? v[0] * inv_keep : 0.f;
+  v[1] = (lo >> 16) >= thresh16 ? v[1] * inv_keep : 0.f;
+  v[2] = (hi & 0xffffu) >= thresh16 ? v[2] * inv_keep : 0.f;
+  v[3] = (hi >> 16) >= thresh16 ? v[3] * inv_keep : 0.f;
+}
+// attention probabilities: pairs along the key axis share one finaliser call (the forward's lane holds 4 consecutive keys
+// of one query: 2 calls per 4 elements; the backward's lane holds 4 consecutive queries of one key: 1 call per element).
+// pair index = (row of the [B*H*Tq] x ceil(Tk/2) pair matrix); decision = 16-bit half (j & 1).
+IMT_DEVICE uint32_t attn_drop_word(uint32_t key, uint64_t pair_idx) {
+  return mix32(((uint32_t)pair_idx ^ key) + (uint32_t)(pair_idx >> 32) * 0x85ebca6bU);
+}
+IMT_DEVICE uint32_t attn_drop_word(uint32_t key, uint32_t pair_idx) { return mix32(pair_idx ^ key); }  // same word for indices < 2^32
+IMT_DEVICE bool attn_drop_keep(uint32_t word, int j, uint32_t thresh16) {
+  return ((j & 1) ? (word >> 16) : (word & 0xffffu)) >= thresh16;
+}
+// p -> 16-bit threshold (0 = dropout off)
 static inline uint32_t dropout_thresh(float p) {
   if (p <= 0.f) return 0u;
-  double t = (double)p * 4294967296.0;
-  if (t > 4294967295.0) t = 4294967295.0;
+  double t = (double)p * 65536.0 + 0.5;
+  if (t > 65535.0) t = 65535.0;
+  if (t < 1.0) t = 1.0;
   return (uint32_t)t;
 }

@@ -277,9 +277,13 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
         for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
       }
       if (KIND == EM_DROP_RESID) {
+        if ((N & 3) == 0) {  // n % 4 == 0: the lane's four elements are one block of the dropout generator
+          dropout_apply4(v, ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, ep.drop_thresh, ep.inv_keep);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? v[e] * ep.inv_keep : 0.f;
+          for (int e = 0; e < 4; ++e)
+            v[e] = dropout_keep(ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), ep.drop_thresh) ? v[e] * ep.inv_keep : 0.f;
+        }
       }
       if (KIND == EM_RESID || KIND == EM_DROP_RESID || KIND == EM_ACC) v += Vec4<T>::cvt(pr[gq]);
       if (KIND == EM_F32_ACC) v += pc[gq];

@@ -193,11 +193,7 @@ __global__ __launch_bounds__(LN_THREADS) void gemm_ln_kernel(GemmLnP p) {
       const int n = wn + 16 * j + 4 * g;
       f32x4 v = acc[i][j];
       if (p.has_bias) v += Vec4<T>::cvt(rb[j]);
-      if (p.drop_thresh) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = dropout_keep(p.seed, (uint64_t)m * (uint64_t)N + (uint64_t)(n + e), p.drop_thresh) ? v[e] * p.inv_keep : 0.f;
-      }
+      if (p.drop_thresh) dropout_apply4(v, p.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, p.drop_thresh, p.inv_keep);
       if (p.has_resid) v += Vec4<T>::cvt(rres[i][j]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {

@@ -99,10 +99,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnSrc<T> src, const T* __re
       const f32x4 g = gv[i], b = bv[i];
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        if (thresh) o[e] = dropout_keep(seed, (uint64_t)row * d + c + e, thresh) ? o[e] * inv_keep : 0.f;
-      }
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if (thresh) dropout_apply4(o, seed, (uint64_t)row * d + c, thresh, inv_keep);
       Vec4<T>::store(yr + c, o);
     }
   }
@@ -165,9 +163,9 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
       for (int i = 0; i < NCH; ++i) {
         const int c = lane * 4 + i * 256;
         if (c < d) {
+          if (y_thresh) dropout_apply4(db[k][i], y_seed, (uint64_t)row * d + c, y_thresh, y_inv_keep);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (y_thresh) db[k][i][e] = dropout_keep(y_seed, (uint64_t)row * d + c + e, y_thresh) ? db[k][i][e] * y_inv_keep : 0.f;
             xb[k][i][e] = (xb[k][i][e] - mu) * rs;
             const float dg = db[k][i][e] * g[i][e];
             s1 += dg;
@@ -188,10 +186,8 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ 
           for (int e = 0; e < 4; ++e) o[e] = rs * (db[k][i][e] * g[i][e] - c1 - xb[k][i][e] * c2);
           Vec4<T>::store(dx + (int64_t)row * d + c, o);
           if (dx_drop) {
-            f32x4 o2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o2[e] = (!dx_thresh || dropout_keep(dx_seed, (uint64_t)row * d + c + e, dx_thresh)) ? o[e] * dx_inv_keep : 0.f;
+            f32x4 o2 = o;
+            if (dx_thresh) dropout_apply4(o2, dx_seed, (uint64_t)row * d + c, dx_thresh, dx_inv_keep);
             Vec4<T>::store(dx_drop + (int64_t)row * d + c, o2);
           }
         }
@@ -404,10 +400,7 @@ __global__ __launch_bounds__(256) void add_rows_dropout_kernel(const TI* __restr
   for (int c = lane * 4; c < d; c += 256) {
     f32x4 v = Vec4<TI>::load(x + r * d + c);
     if (ar) v += Vec4<TO>::load(ar + c);
-    if (thresh) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = dropout_keep(seed, (uint64_t)r * d + c + e, thresh) ? v[e] * inv_keep : 0.f;
-    }
+    if (thresh) dropout_apply4(v, seed, (uint64_t)r * d + c, thresh, inv_keep);
     Vec4<TO>::store(out + r * d + c, v);
   }
 }

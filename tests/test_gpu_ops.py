@@ -667,7 +667,8 @@ def test_gemm_bias_residual_ln_matches_separate_kernels(cuda, dtype, shape):
             # the dropped positions (pre-LN == residual exactly) are the same in both paths, up to the rare element whose
             # product is below half an ulp of the residual in one summation order and not in the other
             da, db = (pre == res if with_res else pre == 0), (pre2 == res if with_res else pre2 == 0)
-            assert abs(float(da.float().mean()) - p) < 0.01 and float((da != db).float().mean()) < 1e-4, "dropout masks differ"
+            rate_tol = 4.0 * math.sqrt(p * (1 - p) / da.numel()) + 0.002
+            assert abs(float(da.float().mean()) - p) < rate_tol and float((da != db).float().mean()) < 1e-4, "dropout masks differ"
         tol = 1e-5 if dtype == torch.float32 else 3.2e-2  # bf16: a rounding step of the pre-LN value and one of the output
         assert_close(out, out2.float().cpu(), tol, "fused LN output vs separate kernels")
         stol = 1e-5 if dtype == torch.float32 else 2e-3  # bf16: statistics of pre-LN values that differ by rounding steps
