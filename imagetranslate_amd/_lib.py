@@ -182,6 +182,13 @@ SIGNATURES = {
     "imt_cast_f32_to_bf16": (c_int, [_P, _P, c_int64, _P]),
     "imt_gated_mix": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, _P]),
     "imt_add_rows_dropout": (c_int, [c_int, _P, c_int, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, _P]),
+    "imt_comm_unique_id_bytes": (c_int, []),
+    "imt_comm_get_unique_id": (c_int, [_P]),
+    "imt_comm_init": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    "imt_comm_allreduce": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "imt_comm_broadcast": (c_int, [_P, _P, c_int64, c_int, c_int, _P]),
+    "imt_comm_destroy": (c_int, [_P]),
+    "imt_set_gemm_share_cus": (c_int, [c_int]),
     "imt_debug_spin": (c_int, [c_int, c_int, c_int, c_int64, _P]),
     "imt_prof_enable": (c_int, [c_int]),
     "imt_prof_report": (c_int, [POINTER(ProfRow), c_int]),

@@ -1150,6 +1150,20 @@ static int gemm_splitk_slabs(const imt_gemm_args* a, void* stream) {
   return IMT_OK;
 }
 
+// one-tile-per-CU GEMMs on the three-workgroups-per-CU kernel (data-parallel runs): imt_set_gemm_share_cus, overridden by the
+// environment variable IMT_GEMM_SHARE_CUS=0|1
+static int g_share_cus = 0;
+static bool share_cus_policy() {
+  static const char* env = getenv("IMT_GEMM_SHARE_CUS");
+  if (env) return atoi(env) != 0 || env[0] == '\0';
+  return g_share_cus != 0;
+}
+extern "C" int imt_set_gemm_share_cus(int share_cus) {
+  const int prev = g_share_cus;
+  g_share_cus = share_cus ? 1 : 0;
+  return prev;
+}
+
 extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   IMT_CHECK_ARG(a != nullptr, "imt_gemm: null args");
   IMT_CHECK_ARG(a->dtype == IMT_F32 || a->dtype == IMT_BF16, "imt_gemm: bad dtype %d", a->dtype);
@@ -1239,8 +1253,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     if (!no_xl && !no_xl_tn && pipe_ok && splits == 1 && a->layout == IMT_TN && tiles256 >= 224 && tiles256 <= 256 && a->K >= 2048) variant = 6;
     // data-parallel knob (off by default): when a collective's kernels hold some CUs, a persistent
     // launch of exactly one tile per CU needs a full second round; three small workgroups per CU degrade gracefully
-    static const bool prefer_small = getenv("IMT_GEMM_SHARE_CUS") != nullptr;
-    if (prefer_small && variant == 5 && a->layout != IMT_TN && tiles > 192 && tiles <= 256 && a->K < 1024) variant = 3;
+    if (share_cus_policy() && variant == 5 && a->layout != IMT_TN && tiles > 192 && tiles <= 256 && a->K < 1024) variant = 3;
   }
   if (variant == 6 && (!pipe_ok || splits > 1 || (a->a_colsum && a->layout != IMT_TN))) variant = 3;
   if ((variant == 2 || variant == 4) && !pipe_ok) variant = 1;

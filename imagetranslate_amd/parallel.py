@@ -25,12 +25,94 @@ import torch.distributed as dist
 from .param_store import FlatParams, store_of
 
 
+class _StreamWork:
+    """Handle of a collective enqueued on the communicator's side stream: wait() makes the CURRENT stream wait for it
+    (no host blocking), like the Work objects of torch's nccl backend."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class RcclComm:
+    """RCCL through the library's own C ABI (imt_comm_*, include/imt_hip.h) -- the exchange without torch.distributed's
+    nccl backend in the data path.  The 128-byte unique id travels through whatever torch.distributed group exists (gloo
+    or nccl; object broadcast) or, for a single rank, nowhere.  Collectives run on a side HIP stream of the communicator's
+    own: launch order on it = call order, the caller's stream is joined by events."""
+
+    def __init__(self, rank: int, world_size: int, group=None):
+        import ctypes
+        from . import _lib as L
+        self._L, self._ct = L, ctypes
+        lib = L.load()
+        n = lib.imt_comm_unique_id_bytes()
+        raw = ctypes.create_string_buffer(n)
+        if rank == 0:
+            L.check(lib.imt_comm_get_unique_id(raw), "imt_comm_get_unique_id")
+        if world_size > 1:
+            box = [bytes(raw.raw) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            raw = ctypes.create_string_buffer(box[0], n)
+        self.rank, self.world_size = rank, world_size
+        self.handle = ctypes.c_void_p()
+        L.check(lib.imt_comm_init(raw, world_size, rank, ctypes.byref(self.handle)), "imt_comm_init")
+        self.stream = torch.cuda.Stream()
+
+    def _enqueue(self, fn):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())   # the buffer's producers are enqueued before this point
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            fn(self._ct.c_void_p(self.stream.cuda_stream))
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return _StreamWork(done)
+
+    def _dtype(self, t):
+        from . import hip_ops as O
+        return O.dt(t)
+
+    def all_reduce_async(self, t: torch.Tensor):
+        """In-place sum over the ranks of a contiguous fp32 / bf16 tensor; returns a handle with wait()."""
+        assert t.is_cuda and t.is_contiguous()
+        lib, L = self._L.load(), self._L
+        return self._enqueue(lambda st: L.check(lib.imt_comm_allreduce(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(),
+                                                                       self._dtype(t), st), "imt_comm_allreduce"))
+
+    def broadcast(self, t: torch.Tensor, root: int = 0):
+        assert t.is_cuda and t.is_contiguous()
+        lib, L = self._L.load(), self._L
+        self._enqueue(lambda st: L.check(lib.imt_comm_broadcast(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(), self._dtype(t),
+                                                                root, st), "imt_comm_broadcast")).wait()
+
+    def destroy(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            self._L.check(self._L.load().imt_comm_destroy(self.handle), "imt_comm_destroy")
+            self.handle = self._ct.c_void_p()
+
+
 class GradSync:
-    def __init__(self, model, process_group=None, bucket_bytes: int = 32 << 20, broadcast_params: bool = True):
+    def __init__(self, model, process_group=None, bucket_bytes: int = 32 << 20, broadcast_params: bool = True,
+                 comm: Optional[RcclComm] = None):
+        """``comm``: an RcclComm -> the buckets go through imt_comm_allreduce (RCCL behind the library's C ABI) instead of
+        ``torch.distributed.all_reduce``; also selected by IMT_COMM=rccl when torch.distributed runs the nccl backend."""
         self.model = model
         self.group = process_group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if comm is None and self.world_size > 1 and os.environ.get("IMT_COMM") == "rccl":
+            comm = RcclComm(dist.get_rank(process_group), self.world_size, process_group)
+        self.comm = comm
+        if comm is not None:
+            self.world_size = comm.world_size
+        if self.world_size > 1 and next(model.parameters()).is_cuda:
+            # a collective's resident kernels hold CUs for milliseconds: one-tile-per-CU GEMMs then need a second round on the
+            # persistent kernel; the three-workgroups-per-CU kernel degrades gracefully (DESIGN.md section 6)
+            from . import _lib as L
+            L.load().imt_set_gemm_share_cus(1)
         self._works: List = []
         self._ready = 0       # elements of the flat gradient buffer that are final (prefix)
         self._next = 0        # index of the next bucket of the schedule to launch
@@ -41,8 +123,11 @@ class GradSync:
         self._layout_version = self.store.layout_version
         self.store.segment_hook = self._on_segment
         self.store.output_hook = self.output_layers_done
-        if broadcast_params and self.world_size > 1:
-            dist.broadcast(self.store.flat, src=0, group=process_group)  # DDP ctor broadcast
+        if broadcast_params and self.world_size > 1:  # DDP ctor broadcast
+            if self.comm is not None:
+                self.comm.broadcast(self.store.flat, 0)
+            else:
+                dist.broadcast(self.store.flat, src=0, group=process_group)
             self.store.mark_master_changed()
         self.launched_buckets = []  # (start, end) of the last step, for tests / tuning
 
@@ -147,7 +232,10 @@ class GradSync:
         self._ready = max(self._ready, ready_end)
         while self._next < len(self._schedule) and self._schedule[self._next][1] <= self._ready:
             s, e = self._schedule[self._next]
-            self._works.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.comm is not None:
+                self._works.append(self.comm.all_reduce_async(self.store.grad[s:e]))
+            else:
+                self._works.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.launched_buckets.append((s, e))
             self._next += 1
 

@@ -244,6 +244,27 @@ int imt_xent_fused_fwd_bwd(int dtype, void* logits, int64_t ld, const int64_t* t
 /* out[0] = scale * sum(x[0..n)), fixed summation order: the `.mean()` of the per-row losses (train_image_mt.py:282). */
 int imt_scaled_sum(const float* x, int n, float scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------ data-parallel gradient exchange (RCCL over xGMI)
+ * Replaces torch DistributedDataParallel's NCCL all-reduce of src/train_image_mt.py:72-76 (bootstrap src/utils.py:93-97):
+ * one process per GPU, one communicator per process.  Rank 0 calls imt_comm_get_unique_id and hands the
+ * imt_comm_unique_id_bytes() (= 128) HOST bytes to every rank out of band; every rank then calls imt_comm_init with the
+ * same id.  imt_comm_allreduce: in-place SUM of `count` elements over the ranks, asynchronous in `stream` (issue one call
+ * per gradient bucket as the backward finalises it; fold 1 / world_size into imt_clip_adam's grad_scale);
+ * imt_comm_broadcast: rank `root`'s buffer to all (the parameter broadcast of DDP's constructor).  librccl is opened at
+ * first use (no load-time dependency); every function returns IMT_ERR_* with a message on RCCL errors. */
+int imt_comm_unique_id_bytes(void);
+int imt_comm_get_unique_id(void* host_id_out);
+int imt_comm_init(const void* host_unique_id, int world_size, int rank, void** comm_out);
+int imt_comm_allreduce(void* comm, void* buf, int64_t count, int dtype, void* stream);
+int imt_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, void* stream);
+int imt_comm_destroy(void* comm);
+
+/* GEMM selection policy for data-parallel runs: share_cus != 0 makes the one-tile-per-CU products with K < 1024 take the
+ * three-workgroups-per-CU kernel instead of the persistent one-workgroup-per-CU kernel, which needs a whole second round
+ * as soon as a collective's resident kernels hold a few CUs.  Returns the previous setting.
+ * The environment variable IMT_GEMM_SHARE_CUS (0 / 1), when set, overrides this call. */
+int imt_set_gemm_share_cus(int share_cus);
+
 /* ------------------------------------------------------------------ optimizer
  * (clip_grad_norm_ train_image_mt.py:291 ; AdamInverseSqrtWithWarmup src/utils.py:105-156)
  * imt_sumsq       : out[0] += sum(g^2) over n fp32 elements (out pre-zeroed by caller); DETERMINISTIC (fixed

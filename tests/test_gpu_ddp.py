@@ -101,3 +101,68 @@ def test_two_ranks_on_one_gpu_match_single_process(cuda):
     for k in KEYS:
         a, b = named[k].detach().float().cpu(), res[0][3][k]
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), k
+
+
+def test_rccl_through_the_c_abi_single_rank(cuda):
+    """imt_comm_* (RCCL opened by the library itself) with the one GPU of the test box: unique id -> communicator of one rank ->
+    in-place all-reduce (identity for one rank) and broadcast on the communicator's side stream, ordered against the caller's
+    stream by events; then GradSync driving its static bucket schedule through it."""
+    import ctypes
+    from imagetranslate_amd import _lib as L
+    from imagetranslate_amd.parallel import GradSync, RcclComm
+    from imagetranslate_amd.param_store import store_of
+    lib = L.load()
+    assert lib.imt_comm_unique_id_bytes() == 128
+    comm = RcclComm(0, 1)
+    x = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+    y = x * 2.0                      # producer on the current stream
+    w = comm.all_reduce_async(y)     # must run after it
+    w.wait()
+    z = y + 1.0                      # consumer on the current stream: after the collective
+    torch.cuda.synchronize()
+    assert torch.equal(z, x * 2.0 + 1.0)
+    b = torch.randn(4096, device="cuda").bfloat16()
+    ref = b.clone()
+    comm.all_reduce_async(b).wait()
+    comm.broadcast(b, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(b, ref)
+    # argument checks
+    assert lib.imt_comm_allreduce(None, None, 4, 0, None) == -1
+    assert lib.imt_comm_init(None, 1, 0, None) == -1
+    # GradSync over the communicator (world of one: forced through the exchange path by pretending two ranks' schedule)
+    m = _model()
+    sync = GradSync(m, comm=comm, bucket_bytes=256 << 10)
+    st = store_of(m.encoder)
+    sync.world_size = 2  # drive the schedule; the communicator itself has one rank, so sums are identities
+    sync.begin_step()
+    st.grad.fill_(1.5)
+    sync.output_layers_done()
+    for mod, l in [(m.decoder, 1), (m.decoder, 0), (m.encoder, 1), (m.encoder, 0)]:
+        sync._on_segment(mod, l)
+    scale = sync.finish()
+    torch.cuda.synchronize()
+    assert scale == 0.5 and sync.launched_buckets == sync.bucket_schedule(None) and bool((st.grad == 1.5).all())
+    lib.imt_set_gemm_share_cus(0)
+    comm.destroy()
+
+
+def test_bench_two_ranks_through_the_plain_command_line(cuda):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its own two rank processes.  On the one-GPU
+    test box both ranks share cuda:0 and gloo carries the collectives (IMT_BENCH_SINGLE_DEVICE / IMT_BENCH_BACKEND, rehearsal
+    knobs); everything else -- per-rank batches, the static bucket schedule with the idle head left out, max-over-ranks timing,
+    rank 0's one JSON line -- is the N > 1 path the driver runs on an 8-GPU node."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(IMT_BENCH_BACKEND="gloo", IMT_BENCH_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "toy", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0
+    full = out["config"]["grad_exchange_bytes_per_step"]
+    assert 0 < full  # the idle language head is left out of the exchange
