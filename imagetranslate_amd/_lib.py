@@ -97,6 +97,7 @@ class StackIO(Structure):
         ("out", c_void_p),
         ("dropout_seed", c_uint64),
         ("d_out", c_void_p), ("d_enc_states", c_void_p),
+        ("wait_events", POINTER(c_void_p)), ("n_wait_events", c_int32), ("reserved2", c_int32),
     ]
 
 

@@ -293,7 +293,18 @@ class _StackFn(torch.autograd.Function):
         if mod.__dict__.get("_imt_params_lo_key") != lo_key:
             mod.__dict__["_imt_params_lo"] = min(store.offset(p) for p in mod.parameters())
             mod.__dict__["_imt_params_lo_key"] = lo_key
-        params = store.params_for(dtype, lo=mod.__dict__["_imt_params_lo"])
+        ev_arr = None
+        handles = store.site_events(mod) if not desc.is_decoder else None
+        if handles is not None:
+            # the encoder is the first consumer of an overlapped optimizer step: instead of waiting for its whole parameter
+            # range here, hand the runtime one event per site (embeddings, layer 0, 1, ...) -- the update runs ahead of the
+            # forward layer by layer (FlatParams.site_events)
+            params = store.params_for(dtype, lo=None)
+            ev_arr = (ctypes.c_void_p * len(handles))(*handles)
+            io.wait_events = ctypes.cast(ev_arr, ctypes.POINTER(ctypes.c_void_p))
+            io.n_wait_events = len(handles)
+        else:
+            params = store.params_for(dtype, lo=mod.__dict__["_imt_params_lo"])
         desc.params = params.data_ptr()
         desc.grads = store.grad.data_ptr()
         lib = L.load()
@@ -306,6 +317,7 @@ class _StackFn(torch.autograd.Function):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(lib.imt_stack_forward(ctypes.byref(desc), ctypes.byref(io), ctypes.c_void_p(ws.data_ptr()), ws_bytes, st),
                 "imt_stack_forward")
+        io.wait_events, io.n_wait_events = None, 0  # (forward only; the handles' array dies with this frame)
         ctx.mod, ctx.store, ctx.dtype, ctx.io, ctx.ws, ctx.ws_bytes = mod, store, dtype, io, ws, ws_bytes
         ctx.keep = (ids, type_ids, pos_ids, key_mask, query_mask, mask3d, enc_mask, enc_states, params)
         # the output goes through save_for_backward: held as a plain attribute it would close a reference cycle
@@ -350,6 +362,9 @@ class _StackFn(torch.autograd.Function):
                                                ctx.ws_bytes, 0, 0, st), "imt_stack_backward")
         store.attach_grad_views()
         ctx.ws = ctx.keep = None
+        done = getattr(store, "stack_done_hook", None)
+        if done is not None:
+            done(mod, ctx.is_decoder)  # e.g. the optimizer's partial gradient norm of everything but the encoder's range
         return (None, d_enc) + (None,) * 13
 
 

@@ -110,7 +110,9 @@ __global__ void spin_kernel(long long cycles, int lds_bytes) {
 }  // namespace
 
 extern "C" int imt_debug_spin(int blocks, int threads, int lds_bytes, int64_t cycles, void* stream) {
-  IMT_CHECK_ARG(blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 65536 && cycles >= 0, "debug_spin: bad args");
+  IMT_CHECK_ARG(blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && cycles >= 0, "debug_spin: bad args");
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, (long long)cycles, lds_bytes);
   IMT_CHECK_LAUNCH();
   return IMT_OK;

@@ -380,6 +380,12 @@ extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io
   const bool training = io->training != 0;
   const uint64_t seed = io->dropout_seed;
   void* x0 = (m->n_layers == 0) ? io->out : w.x0;
+  // parameters still being written by an optimizer step on another stream: wait site by site (imt_stack_io.wait_events)
+  auto wait_site = [&](int k) {
+    if (io->wait_events && k < io->n_wait_events && io->wait_events[k])
+      (void)hipStreamWaitEvent(c.st, (hipEvent_t)const_cast<void*>(io->wait_events[k]), 0);
+  };
+  wait_site(0);
   // BertEmbeddings: gather + sum + LayerNorm + dropout in one launch (the sum is kept for the backward)
   RC(imt_embed_ln_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), c.P(m->emb_ln_g),
                       c.P(m->emb_ln_b), w.emb_sum, x0, w.emb_mean, w.emb_rstd, N, T, d, m->vocab, m->max_pos, m->n_types, m->ln_eps,
@@ -394,6 +400,7 @@ extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io
   for (int l = 0; l < m->n_layers; ++l) {
     const imt_layer_desc& p = m->layers[l];
     LayerWs& L = layers[l];
+    wait_site(1 + l);
     RC(attn_block_fwd(c, p.self_attn, L.self_attn, x, B, T, nullptr, 0, self_ms, training, seed, l, 0));
     const void* a = L.self_attn.out;
     if (m->is_decoder && p.cross_attn.qkv_w >= 0) {

@@ -3,6 +3,7 @@
 //   (torch.optim.Adam as subclassed by AdamInverseSqrtWithWarmup, src/utils.py:105-156), writing the bf16
 //   shadow copy the MFMA kernels read and zeroing the gradients for the next step in the same pass.
 // HBM-bound: 4 fp32 streams read, 3 written (+1 bf16) per element.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -158,8 +159,12 @@ extern "C" int imt_clip_adam(float* p, float* g, float* m, float* v, void* p_bf1
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.zero_grad = zero_grad;
+  // grid: enough workgroups to saturate HBM when the update runs alone (2048 x 256 threads: every wave slot of the chip).
+  // IMT_ADAM_BLOCKS (tuning): a smaller grid leaves wave slots to the kernels of the next forward when the update runs on a
+  // side stream beside them.
+  static const int cap = getenv("IMT_ADAM_BLOCKS") ? atoi(getenv("IMT_ADAM_BLOCKS")) : 2048;
   int blocks = imt_cdiv(n, 2048);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   ImtProfScope prof("clip_adam", 0.0, (p_bf16 ? 34.0 : 32.0) * n, (hipStream_t)stream);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, sumsq, a);

@@ -264,12 +264,7 @@ def clip_in_place(optimizer, store, max_norm: float, grad_scale: float = 1.0):
     """``clip_grad_norm_`` on the flat gradient buffer, in place (the micro-steps of an accumulation window that do not
     end in an optimizer step: src/train_image_mt.py:291 clips after EVERY backward)."""
     from . import hip_ops as O
-    if optimizer._sumsq is None or optimizer._sumsq.device != store.flat.device:
-        optimizer._sumsq = torch.zeros(1, device=store.flat.device)
-        optimizer._sumsq_ws = torch.empty(1024, device=store.flat.device, dtype=torch.float32)
-    optimizer._sumsq.zero_()
-    O.sumsq(store.grad, optimizer._sumsq, optimizer._sumsq_ws)
-    O.clip_scale(store.grad, optimizer._sumsq, float(max_norm), float(grad_scale))
+    O.clip_scale(store.grad, optimizer._grad_norm_sq(store), float(max_norm), float(grad_scale))
 
 
 def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: float = 1.0, epsilon: float = 0.1,
@@ -290,7 +285,7 @@ def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: f
         scale = sync.finish()
     if update:
         optimizer.step(max_grad_norm=clip, grad_scale=scale, zero_grad=True,
-                       overlap_next_forward=os.environ.get("IMT_ADAM_OVERLAP", "1") != "0")
+                       overlap_next_forward=os.environ.get("IMT_ADAM_OVERLAP", "0") != "0")
     else:
         clip_in_place(optimizer, store_of(model.encoder).ensure(), clip, scale)
     return loss, ntokens

@@ -35,6 +35,7 @@ class FlatParams:
         self.index = {}        # id(param) -> offset
         self.total = 0
         self.layout_version = 0
+        self.grad_generation = 0  # bumped whenever the gradient buffer is zeroed (voids partial sums taken over it)
         self._update_events = []  # (lo, hi, event) of an optimizer step still running on its side stream
 
     # ------------------------------------------------------------------ layout
@@ -117,6 +118,7 @@ class FlatParams:
 
     def zero_grad(self):
         self.wait_updates(0)
+        self.grad_generation += 1
         if self.grad is not None:
             self.grad.zero_()
 
@@ -135,11 +137,38 @@ class FlatParams:
             if lo == 0:
                 self._update_events = []
 
+    def site_events(self, mod):
+        """Per-site events of an overlapped optimizer step for stack ``mod`` -- [embeddings, layer 0, layer 1, ...] as raw
+        hipEvent_t handles (None = nothing to wait for) -- or None when there is no pending step / the bf16 shadow needs a
+        full refresh anyway.  The update segments run on ONE side stream, so waiting for the LAST-issued segment that
+        overlaps a site's parameters covers the earlier ones."""
+        if not self._update_events or self._shadow_stale:
+            return None
+        key = ("_imt_site_ranges", self.layout_version)
+        cached = mod.__dict__.get("_imt_site_ranges")
+        if cached is None or cached[0] != key:
+            def rng(params):
+                ps = [p for p in params if id(p) in self.index]
+                return (min(self.offset(p) for p in ps), max(self.offset(p) + p.numel() for p in ps))
+            sites = [rng(list(mod.embeddings.parameters()))] + [rng(list(l.parameters())) for l in mod._stack_layers()]
+            cached = (key, sites)
+            mod.__dict__["_imt_site_ranges"] = cached
+        out = []
+        for lo, hi in cached[1]:
+            last = None
+            for seg_lo, seg_hi, ev in self._update_events:  # issue order
+                if seg_lo < hi and seg_hi > lo:
+                    last = ev
+            out.append(None if last is None else last.cuda_event)
+        return out
+
     def params_for(self, dtype: torch.dtype, lo: int = 0) -> torch.Tensor:
         """Flat parameter buffer in the compute dtype (fp32 master itself, or the bf16 shadow, refreshed when the
         master changed through torch in-place ops or a fused optimizer step without shadow write).  ``lo``: the caller
-        only reads parameters at offsets >= lo (see wait_updates)."""
-        self.wait_updates(lo)
+        only reads parameters at offsets >= lo (see wait_updates); None: the caller orders itself against the pending
+        update (site_events)."""
+        if lo is not None:
+            self.wait_updates(lo)
         if dtype == torch.float32:
             return self.flat
         assert dtype == torch.bfloat16

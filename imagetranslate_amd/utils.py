@@ -49,6 +49,9 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
             param_group['num_updates'] = 0
         self.max_lr = lr
         self._sumsq = None
+        self._partial = None
+        import os
+        self._partial_ok = os.environ.get("IMT_PARTIAL_NORM", "1") != "0"
         self.last_grad_norm_sq = None  # device tensor of the last fused grad-norm^2 (no host sync)
 
     def get_lr_for_step(self, num_updates):
@@ -103,13 +106,12 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
             m, v = st.moments()
             sumsq = None
             if max_grad_norm and max_grad_norm > 0:
-                if self._sumsq is None or self._sumsq.device != st.flat.device:
-                    self._sumsq = torch.zeros(1, device=st.flat.device)
-                    self._sumsq_ws = torch.empty(1024, device=st.flat.device, dtype=torch.float32)
-                self._sumsq.zero_()
-                O.sumsq(st.grad, self._sumsq, self._sumsq_ws)
-                sumsq = self._sumsq
+                sumsq = self._grad_norm_sq(st)
                 self.last_grad_norm_sq = sumsq
+                if self._partial_ok and getattr(st, "stack_done_hook", None) is None:
+                    st.stack_done_hook = self._stack_done  # from the next backward on: part of the norm under the backward
+            else:
+                self._partial = None
             segs = self._segments(st) if overlap_next_forward else None
             if segs is None:
                 O.clip_adam(st.flat, st.grad, m, v, st.shadow_buffer_for_optimizer(), sumsq, float(max_grad_norm or 0.0),
@@ -134,6 +136,8 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
                         ev.record(self._side)
                         events.append((lo, hi, ev))
                 st._update_events = events
+            if zero_grad:
+                st.grad_generation += 1  # (a partial gradient norm taken before this point is void)
             if st.shadow_buffer_for_optimizer() is not None:
                 st.note_shadow_written_by_optimizer()
             else:
@@ -144,19 +148,76 @@ class AdamInverseSqrtWithWarmup(torch.optim.Optimizer):
 
     @staticmethod
     def _segments(st):
-        """[(lo, hi)] of the flat buffer in the order the next forward needs them: encoder + embeddings (and whatever
-        follows), decoder(s), output layers -- None when the model does not expose that structure."""
+        """[(lo, hi)] of the flat buffer in the order the next forward needs them: embeddings (and whatever follows them),
+        encoder layers 0, 1, ... (each its own segment: the encoder forward waits layer by layer, FlatParams.site_events),
+        decoder(s), output layers -- None when the model does not expose that structure."""
         root = st._root()
         try:
-            enc_first = list(root.encoder.encoder.layer)[-1].ordered_params()[0]
+            enc_layers = list(root.encoder.encoder.layer)
+            starts = [min(st.offset(p) for p in lyr.ordered_params()) for lyr in enc_layers]  # flat order: top layer first
+            e = root.encoder.embeddings
+            emb_lo = min(st.offset(p) for p in e.parameters())
             decs = list(root.decoder) if isinstance(root.decoder, torch.nn.ModuleList) else [root.decoder]
             dec_lo = min(st.offset(p) for d in decs for p in d.parameters())
-            enc_lo = st.offset(enc_first)
+            enc_lo = min(starts)
         except Exception:
             return None
-        if not (0 < dec_lo < enc_lo < st.total):
+        if not (0 < dec_lo < enc_lo < emb_lo < st.total) or sorted(starts, reverse=True) != starts:
             return None
-        return [(enc_lo, st.total), (dec_lo, enc_lo), (0, dec_lo)]
+        segs = [(emb_lo, st.total)]
+        for l in range(len(enc_layers)):  # layer l spans [its first parameter, the first parameter of layer l - 1 / the embeddings)
+            segs.append((starts[l], starts[l - 1] if l > 0 else emb_lo))
+        segs += [(dec_lo, enc_lo), (0, dec_lo)]
+        return segs
+
+    # ------------------------------------------------------------------ gradient norm, part of it under the backward
+    def _stack_done(self, mod, is_decoder):
+        """FlatParams.stack_done_hook: when the DECODER's backward has been enqueued, every gradient below the encoder's range
+        (output layers, decoder) is final -- its share of the squared norm is summed on the side stream while the encoder's
+        backward runs; step() then only adds the encoder + embedding range.  Fixed order of the two partial sums:
+        deterministic.  Off under a data-parallel exchange (the norm is of the REDUCED gradients) and with IMT_PARTIAL_NORM=0."""
+        if not is_decoder or not self._partial_ok:
+            return  # (the encoder's backward comes after the decoder's and leaves the partial sum valid)
+        self._partial = None
+        st = self._store()
+        if st is None or getattr(st, "segment_hook", None) is not None:
+            return
+        segs = self._segments(st)
+        if segs is None:
+            return
+        enc_lo = segs[-2][1]
+        self._ensure_norm_buffers(st)
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            self._sumsq.zero_()
+            O.sumsq(st.grad[:enc_lo], self._sumsq, self._sumsq_ws_side)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._partial = (enc_lo, done, (st.layout_version, st.grad_generation))
+
+    def _ensure_norm_buffers(self, st):
+        if self._sumsq is None or self._sumsq.device != st.flat.device:
+            self._sumsq = torch.zeros(1, device=st.flat.device)
+            self._sumsq_ws = torch.empty(1024, device=st.flat.device, dtype=torch.float32)
+            self._sumsq_ws_side = torch.empty(1024, device=st.flat.device, dtype=torch.float32)
+
+    def _grad_norm_sq(self, st):
+        """sum(g^2) over the flat gradient buffer as a device scalar (no host sync)."""
+        self._ensure_norm_buffers(st)
+        part, self._partial = getattr(self, "_partial", None), None
+        if part is not None and part[2] == (st.layout_version, st.grad_generation):
+            enc_lo, done, _ = part
+            torch.cuda.current_stream().wait_event(done)
+            O.sumsq(st.grad[enc_lo:], self._sumsq, self._sumsq_ws)  # adds to the partial sum
+        else:
+            self._sumsq.zero_()
+            O.sumsq(st.grad, self._sumsq, self._sumsq_ws)
+        return self._sumsq
 
     def _generic_step(self, max_grad_norm, grad_scale):
         params = [p for g in self.param_groups for p in g['params'] if p.grad is not None]

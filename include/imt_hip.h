@@ -355,6 +355,13 @@ typedef struct imt_stack_io {
   /* backward only */
   const void* d_out;         /* [B,T,d] gradient of `out` */
   void* d_enc_states;        /* decoder: [B,Tk,d] gradient w.r.t. enc_states, OVERWRITTEN */
+  /* forward only, optional: HOST array of n_wait_events hipEvent_t (as void*, NULL entries allowed).  `stream` waits for
+   * wait_events[0] before the embeddings are read and for wait_events[1 + l] before layer l: an optimizer step that is still
+   * updating the parameters on another stream (segment by segment, in the order the forward needs them) then delays only
+   * the layer it has not reached yet instead of the whole stack. */
+  const void* const* wait_events;
+  int32_t n_wait_events;
+  int32_t reserved2;
 } imt_stack_io;
 
 int64_t imt_stack_workspace_bytes(const imt_stack_desc* m, int B, int T, int Tk);
