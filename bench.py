@@ -297,7 +297,7 @@ def main():
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             traffic = None
             try:  # HBM bytes per launch of this kernel kind from the committed PMC passes (tools/collect_traffic.sh)
-                pt = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                pt = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 if args.config == "c1" and world == 1:
                     traffic = round(pt["per_kind"][dom["kind"]]["hbm_bytes_per_launch"])
             except Exception:

@@ -593,7 +593,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
   char* epi = smem + WS_NST * STAGE_BYTES;
   const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
   const int tiles = nbx * nby;
-  const int nt = K / BK;
+  // whole K tiles for NT / NN (host-checked).  TN (weight gradients: K = token count, any value): both operands are K-STRIDED,
+  // so the rows of a ragged last K tile lie past the operands' valid bytes and the descriptors' range check fills them with
+  // zeros -- they add nothing to the products (or to the fused column sums)
+  const int nt = (K + BK - 1) / BK;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool consumer = wave < 4;
   const int my_tiles = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
   const int bid = imt_xcd_block(blockIdx.x, nbx * nby);
   const int m0 = (bid / nbx) * 256, n0 = (bid % nbx) * 256;
   // split-K slab mode (gridDim.y > 1): this workgroup multiplies K tiles [kt0, kt0 + nt) into its own fp32 slab
-  const int nt_all = K / BK;  // host guarantees whole K tiles
+  const int nt_all = (K + BK - 1) / BK;  // whole K tiles for NT / NN (host-checked); TN: a ragged last tile reads zeros (range check)
   const int per = (nt_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int kt0 = (int)blockIdx.y * per;
   const int nt = max(0, min(per, nt_all - kt0));
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
   const int nbx = (N + BN - 1) / BN;
   const int local = bid - P.tile_start;
   const int m0 = (local / nbx) * BM, n0 = (local % nbx) * BN;
-  const int nt = K / BK;
+  const int nt = (K + BK - 1) / BK;  // a ragged last K tile (token counts are arbitrary) reads zeros past the operands' valid bytes
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool consumer = wave < 4;
   const int wm = ((wave & 3) >> 1) * 64, wn = (wave & 1) * 64;
@@ -1205,13 +1208,14 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   if (a->aux_mode != IMT_AUX_NONE) IMT_CHECK_ARG(a->aux != nullptr, "imt_gemm: aux_mode needs aux");
   // LDS-DMA pipeline: whole K tiles only (no zero-fill needed anywhere), 32-bit buffer offsets
   const int64_t a_rows = (a->layout == IMT_TN) ? a->K : a->M, b_rows = (a->layout == IMT_NT) ? a->N : a->K;
-  const bool pipe_ok = (a->K % bk == 0) && (a->K / bk >= 2) && (a_rows * a->lda * es < (1ll << 31)) &&
+  // (TN: K-strided operands, a ragged last K tile is zero-filled by the descriptors' range check -- any K)
+  const bool pipe_ok = (a->K % bk == 0 || a->layout == IMT_TN) && (a->K / bk >= 2) && (a_rows * a->lda * es < (1ll << 31)) &&
                        (b_rows * a->ldb * es < (1ll << 31));
   // Long K that is not a whole number of tiles (the vocabulary dimension: dX = dlogits[.,30000] W): the LDS-DMA
   // kernels need whole K tiles, so the ragged tail goes first as its own small product and the whole-tile body is
   // accumulated on top by the persistent kernel (477 -> ~700 TFLOP/s on 8128x512x30000).  Only for epilogues that are
   // linear in the product (bias / residual ride on the tail call).
-  if (a->force_general == 0 && splits == 1 && a->K % bk != 0 && a->K / bk >= 16 && a->aux_mode == IMT_AUX_NONE &&
+  if (a->force_general == 0 && splits == 1 && a->layout != IMT_TN && a->K % bk != 0 && a->K / bk >= 16 && a->aux_mode == IMT_AUX_NONE &&
       a->dropout_p == 0.f && !a->a_colsum) {
     const int kb = (a->K / bk) * bk, kt = a->K - kb;
     imt_gemm_args tail = *a, body = *a;
@@ -1287,7 +1291,7 @@ extern "C" int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* s
     const imt_gemm_args& a = list[i];
     ok = a.dtype == dtype && a.layout == IMT_TN && a.c_dtype == IMT_F32 && !a.bias && !a.resid && a.aux_mode == IMT_AUX_NONE &&
          a.dropout_p == 0.f && !a.alpha_dev && a.alpha == list[0].alpha && a.A && a.B && a.C && a.M > 0 && a.N > 0 &&
-         a.K % bk == 0 && a.K / bk >= 2 && a.lda % al == 0 && a.ldb % al == 0 && a.M % al == 0 && a.N % al == 0 && a.ldc % 4 == 0 &&
+         a.K / bk >= 2 && a.lda % al == 0 && a.ldb % al == 0 && a.M % al == 0 && a.N % al == 0 && a.ldc % 4 == 0 &&
          (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 && (int64_t)a.K * a.lda * es < (1ll << 31) &&
          (int64_t)a.K * a.ldb * es < (1ll << 31);
     tiles += imt_cdiv(a.M, BM) * imt_cdiv(a.N, BN);

@@ -254,12 +254,15 @@ def test_gemm_tn_fused_bias_gradient(cuda, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_grouped_weight_gradients(cuda, dtype):
-    """imt_gemm_grouped_tn: the 4..7 weight-gradient GEMMs of a layer in one launch == the individual results;
-    ragged token counts fall back to individual launches (same answers)."""
+    """imt_gemm_grouped_tn: the 4..7 weight-gradient GEMMs of a layer in one launch == the individual results; token counts
+    that are not a whole number of K tiles (520, 992: real batches) take the same launch -- the rows of the ragged last K tile
+    lie past the operands' valid bytes and the LDS-DMA range check zero-fills them (the memory behind the operands here is
+    whatever the allocator left there)."""
     from imagetranslate_amd import hip_ops as O
     g = torch.Generator().manual_seed(13)
     tol = 2e-5 if dtype == torch.float32 else 1e-2
-    for tokens in (512, 520):  # 520 is not a whole number of K tiles -> fallback path
+    torch.full((1 << 22,), 7.0, device=cuda)  # poison recycled allocator blocks: a read past an operand would not see zeros
+    for tokens in (512, 520, 992):
         shapes = [(384, 128), (128, 128), (512, 128), (128, 512), (200, 136)]
         probs, refs = [], []
         for (out_f, in_f) in shapes:
@@ -273,6 +276,35 @@ def test_gemm_grouped_weight_gradients(cuda, dtype):
         for pr, (rw, rb) in zip(probs, refs):
             assert_close(pr["out"], rw, tol, "grouped dW (tokens=%d)" % tokens)
             assert_close(pr["a_colsum"], rb, tol, "grouped db (tokens=%d)" % tokens)
+    # one launch also for the ragged counts
+    from imagetranslate_amd import _lib as L
+    lib = L.load()
+    torch.cuda.synchronize()
+    lib.imt_prof_enable(1)
+    O.gemm_grouped_tn(probs)
+    torch.cuda.synchronize()
+    rows = (L.ProfRow * 16)()
+    n = lib.imt_prof_report(rows, 16)
+    lib.imt_prof_enable(0)
+    assert n == 1 and rows[0].kind.decode().endswith("tn_grouped") and rows[0].launches == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_ragged_k_on_the_dma_kernels(cuda, dtype):
+    """Weight-gradient products (TN: K = token count) with a K that is not a whole number of tiles on the persistent and the
+    256-tile kernels (variants 5 / 6): the ragged last K tile is zero-filled by the descriptors' range check."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(31)
+    torch.full((1 << 22,), 5.0, device=cuda)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    for variant, (K, M, N) in ((5, (1000, 256, 384)), (6, (2100, 512, 256)), (5, (72, 128, 128))):
+        dy, dyf = _mk((K, M), dtype, cuda, 1.0, g)
+        x, xf = _mk((K, N), dtype, cuda, 1.0, g)
+        gw0 = torch.randn((M, N), generator=g); gb0 = torch.randn(M, generator=g)
+        gw, gb = gw0.clone().to(cuda), gb0.clone().to(cuda)
+        O.gemm(dy, x, O.IMT_TN, out=gw, accumulate=True, a_colsum=gb, force_general=variant)
+        assert_close(gw, gw0 + dyf.t() @ xf, tol, "TN ragged K variant %d" % variant)
+        assert_close(gb, gb0 + dyf.sum(0), tol, "fused bias gradient, ragged K variant %d" % variant)
 
 
 def test_gemm_bad_args(cuda):

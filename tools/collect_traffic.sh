@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the GEMM kernels inside the bench step, by PMC counters (separate passes, counters only), corrected as
 # MI355X_MICROARCH.md "HBM" prescribes: bytes = 2 * FETCH_SIZE*1024 (gfx950 reports half of a wide coalesced read
-# stream) + WRITE_SIZE*1024.  Writes profiles/r01_pmc_traffic.json (per-launch averages per kernel symbol).
+# stream) + WRITE_SIZE*1024.  Writes gpurun_out/pmc_traffic.json (per-launch averages per kernel symbol); tools/make_traffic_json.py turns it into profiles/r<NN>_pmc_traffic.json.
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
