@@ -244,6 +244,10 @@ class Seq2Seq(nn.Module):
 
     def __setattr__(self, name, value):
         super().__setattr__(name, value)
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            st = self.__dict__.get("_imt_flat_store")
+            if st is not None:
+                st.mark_dirty()  # the set of parameters may have changed: next use re-validates the flat store in full
         if isinstance(value, nn.Module) and "_imt_compute_dtype" in self.__dict__:
             self._link_stacks()  # e.g. caption_model.encoder = mt_model.encoder (train_captioning.py:218-220)
 
