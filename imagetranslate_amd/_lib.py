@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libimt_hip.so")
+LIB_PATH = os.environ.get("IMT_LIB") or os.path.join(_HERE, "libimt_hip.so")  # IMT_LIB: another build of the SAME library (A/B runs)
 
 IMT_F32, IMT_BF16 = 0, 1
 IMT_NT, IMT_NN, IMT_TN = 0, 1, 2

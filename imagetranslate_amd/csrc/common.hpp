@@ -53,20 +53,52 @@ void imt_prof_end_launch(void* tok, hipStream_t st);
 #include <stdlib.h>
 struct ImtTrace {
   static constexpr int MAXB = 4096;
+  static constexpr int RING = 64;  // IMT_TRACE_RING=1: no sync per launch; every RING-th traced launch prints the absolute
+                                   // first-start / last-end of the last RING launches (the dark time BETWEEN kernels)
   unsigned long long* dev = nullptr;
   const char* kind; int blocks; hipStream_t st;
+  struct Slot { const char* kind; int blocks; };
+  static Slot* slots() { static Slot s[RING]; return s; }
+  static int& count() { static int c = 0; return c; }
+  static bool ring() { static const bool r = getenv("IMT_TRACE_RING") != nullptr; return r; }
   ImtTrace(const char* kind_, int blocks_, hipStream_t st_) : kind(kind_), blocks(blocks_), st(st_) {
     static const char* want = getenv("IMT_TRACE");
-    if (!want || strcmp(want, kind_) != 0 || blocks_ > MAXB) return;
+    if (!want || (strcmp(want, kind_) != 0 && strcmp(want, "all") != 0) || blocks_ > MAXB || blocks_ <= 0) return;
     static unsigned long long* buf = nullptr;
-    if (!buf && hipMalloc(&buf, MAXB * 8 * sizeof(unsigned long long)) != hipSuccess) return;
-    (void)hipMemsetAsync(buf, 0, MAXB * 8 * sizeof(unsigned long long), st);
-    dev = buf;
+    const size_t slice = (size_t)MAXB * 8;
+    if (!buf && hipMalloc(&buf, (ring() ? RING : 1) * slice * sizeof(unsigned long long)) != hipSuccess) return;
+    const int slot = ring() ? count() % RING : 0;
+    if (ring()) slots()[slot] = Slot{kind_, blocks_};
+    dev = buf + slot * slice;
+    if (!ring()) (void)hipMemsetAsync(dev, 0, sizeof(unsigned long long) * 8 * blocks_, st);
+    else if (slot == 0) (void)hipMemsetAsync(buf, 0, RING * slice * sizeof(unsigned long long), st);  // once per ring: no fill between launches
   }
   ~ImtTrace() {
     if (!dev) return;
-    (void)hipStreamSynchronize(st);
     static unsigned long long h[MAXB * 8];
+    if (ring()) {
+      if (++count() % RING != 0) return;
+      (void)hipStreamSynchronize(st);
+      unsigned long long* base = dev - (size_t)((count() - 1) % RING) * MAXB * 8;
+      unsigned long long origin = 0, prev_end = 0;
+      for (int s = 0; s < RING; ++s) {
+        const Slot& sl = slots()[s];
+        (void)hipMemcpy(h, base + (size_t)s * MAXB * 8, sizeof(unsigned long long) * 8 * sl.blocks, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
+        for (int i = 0; i < 8 * sl.blocks; ++i) {
+          if (!h[i]) continue;
+          if (h[i] < t0) t0 = h[i];
+          if (h[i] > t1) t1 = h[i];
+          if ((i & 7) == 0 && h[i] > s1) s1 = h[i];
+        }
+        if (!origin) origin = t0;
+        fprintf(stderr, "[ring %2d] %-10s %5d wgs  start %9.2f  last-start +%6.2f  end +%6.2f  dark-before %6.2f us\n", s, sl.kind, sl.blocks,
+                (t0 - origin) * 0.01, (s1 - t0) * 0.01, (t1 - t0) * 0.01, prev_end ? ((double)t0 - (double)prev_end) * 0.01 : 0.0);
+        prev_end = t1;
+      }
+      return;
+    }
+    (void)hipStreamSynchronize(st);
     (void)hipMemcpy(h, dev, sizeof(unsigned long long) * 8 * blocks, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull, t1 = 0;
     double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -116,6 +148,9 @@ template <> IMT_DEVICE float from_f32<float>(float v) { return v; }
 template <> IMT_DEVICE bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
 // 4-element vector of T <-> f32x4 (global/LDS, 8- or 16-byte accesses)
+#ifndef IMT_WT_STORES
+#define IMT_WT_STORES 0
+#endif
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
   typedef f32x4 type;
@@ -133,7 +168,12 @@ template <> struct Vec4<bf16_t> {
   }
   static IMT_DEVICE void store(bf16_t* p, f32x4 v) {
     bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+#if IMT_WT_STORES  // experiment: write-through (sc1) output stores, nothing left dirty for the end-of-kernel write-back
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+#else
     *reinterpret_cast<bf16x4*>(p) = r;
+#endif
   }
   static IMT_DEVICE type load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
   static IMT_DEVICE f32x4 cvt(type v) {

@@ -579,7 +579,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict
 // tile stalls the MFMA waves of the next one.  The epilogue restages through its own 32 KiB (ring 96 KiB + 32 KiB
 // = 128 KiB: a communication workgroup of a data-parallel job can share the CU).  Producers keep their own counted vmcnt (only DMA), consumers' epilogue loads/stores
 // have theirs; the only coupling is one raw s_barrier per K tile plus the epilogue's four.
-constexpr int WS_NST = 3;   // 96 KiB ring + 32 KiB epilogue staging = 128 KiB: leaves LDS for a co-resident communication workgroup
+#ifndef IMT_WS_NST
+#define IMT_WS_NST 3
+#endif
+#ifndef IMT_WS_ROTATE
+#define IMT_WS_ROTATE 0
+#endif
+constexpr int WS_NST = IMT_WS_NST;   // 96 KiB ring + 32 KiB epilogue staging = 128 KiB: leaves LDS for a co-resident communication workgroup
 constexpr int WS_THREADS = 512;
 constexpr int WS_LDS = WS_NST * STAGE_BYTES + 32768;
 
@@ -607,14 +613,20 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
     Dma<T, A_KC> da; Dma<T, B_KC> db;
     const int total = my_tiles * nt;
     int iq = 0, tq = 0;  // tile / k index of the NEXT step to issue
+    int rot = 0;
     auto issue_next = [&](int slot) {
       if (tq == 0) {
         const int lt = imt_xcd_block(blockIdx.x + iq * gridDim.x, tiles);
         da.init(A, lda, a_bytes, (lt / nbx) * BM, 0, wave - 4);
         db.init(B, ldb, b_bytes, (lt % nbx) * BN, 0, wave - 4);
+        // (experiment) the workgroups that share an operand row block start at different K tiles, so a tile is
+        // fetched from the Infinity Cache by one of them and found in the XCD's L2 by the others
+        if (IMT_WS_ROTATE && sizeof(T) == 2) rot = ((lt % nbx) * nt / nbx + (lt / nbx)) % nt;
       }
-      da.issue(smem + slot * STAGE_BYTES, tq);
-      db.issue(smem + slot * STAGE_BYTES + TILE_BYTES, tq);
+      int tk = tq + rot;
+      if (tk >= nt) tk -= nt;
+      da.issue(smem + slot * STAGE_BYTES, tk);
+      db.issue(smem + slot * STAGE_BYTES + TILE_BYTES, tk);
       if (++tq == nt) { tq = 0; ++iq; }
     };
     int issued = 0;
@@ -624,7 +636,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
     int cur = 0, t = 0;
     for (int q = 0; q < total; ++q) {
       const int newer = issued - 1 - q;  // steps issued after step q (0 .. WS_NST-2)
-      if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (WS_NST >= 4 && newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
@@ -974,7 +987,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
       const int newer = min(GROUP_NST - 2, nt - 1 - t);
-      if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (WS_NST >= 4 && newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");

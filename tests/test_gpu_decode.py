@@ -97,10 +97,38 @@ def _ref_beam_step(logits, scores, sizes, eos_in, max_lens, hist, step, B, beam,
     return top.view(-1), new_sizes, new_eos, new_hist, prow
 
 
-@pytest.mark.parametrize("beam,step", [(4, 1), (4, 3), (1, 1), (1, 4), (7, 2)])
-def test_beam_step_matches_reference_step(cuda, beam, step):
+def _call_beam_step(logits, scores, sizes, eos_in, max_lens, hist, slots_in, step, B, beam, rep, V, t_max, ratio, pad, eos):
+    """One imt_beam_step through the C ABI on copies of the given CPU tensors; returns the output buffers."""
     import imagetranslate_amd.hip_ops as O
     from imagetranslate_amd import _lib as L
+    dev = "cuda"
+    rows, r_out = B * rep, B * beam
+    z = lambda *s, dtype: torch.zeros(*s, dtype=dtype, device=dev)
+    d_logits, d_scores, d_sizes = logits.cuda(), scores.cuda(), sizes.cuda()
+    d_eos, d_max, d_hist = eos_in.to(torch.uint8).cuda(), max_lens.cuda(), hist.cuda()
+    d_slots = slots_in.cuda()
+    cs, ci = z(rows, beam, dtype=torch.float32), z(rows, beam, dtype=torch.int32)
+    o_scores, o_sizes, o_eos = z(r_out, dtype=torch.float32), z(r_out, dtype=torch.float32), z(r_out, dtype=torch.uint8)
+    o_hist, o_slots = z(r_out, t_max, dtype=torch.int64), z(r_out, t_max, dtype=torch.int32)
+    o_parent, o_tok, cnt = z(r_out, dtype=torch.int32), z(r_out, dtype=torch.int64), z(t_max, dtype=torch.int32)
+    a = L.BeamArgs()
+    a.B, a.beam, a.rep, a.V, a.step, a.t_max = B, beam, rep, V, step, t_max
+    a.logits, a.ld = d_logits.data_ptr(), V
+    a.scores_in, a.sizes_in, a.eos_in = d_scores.data_ptr(), d_sizes.data_ptr(), d_eos.data_ptr()
+    a.max_lens, a.hist_in, a.slots_in = d_max.data_ptr(), d_hist.data_ptr(), d_slots.data_ptr()
+    a.len_penalty_ratio, a.pad_idx, a.eos = ratio, pad, eos
+    a.cand_scores, a.cand_idx = cs.data_ptr(), ci.data_ptr()
+    a.scores_out, a.sizes_out, a.eos_out = o_scores.data_ptr(), o_sizes.data_ptr(), o_eos.data_ptr()
+    a.hist_out, a.slots_out, a.parent_out, a.tokens_out = o_hist.data_ptr(), o_slots.data_ptr(), o_parent.data_ptr(), o_tok.data_ptr()
+    a.eos_count = cnt.data_ptr()
+    O.beam_step(a)
+    torch.cuda.synchronize()
+    return dict(scores=o_scores.cpu(), sizes=o_sizes.cpu(), eos=o_eos.cpu(), hist=o_hist.cpu(), slots=o_slots.cpu(),
+                parent=o_parent.cpu(), tokens=o_tok.cpu(), eos_count=cnt.cpu(), cand_idx=ci.cpu(), cand_scores=cs.cpu())
+
+
+@pytest.mark.parametrize("beam,step", [(4, 1), (4, 3), (1, 1), (1, 4), (7, 2)])
+def test_beam_step_matches_reference_step(cuda, beam, step):
     g = torch.Generator().manual_seed(beam * 10 + step)
     B, V, t_max, pad, eos, ratio = 5, 300, 8, 0, 4, 0.8
     rep = 1 if step == 1 else beam
@@ -125,27 +153,11 @@ def test_beam_step_matches_reference_step(cuda, beam, step):
     max_lens = torch.tensor([step + 1, step, 9, 9, step - 1])   # sentences 1 and 4 over the limit when step > 1
     exp = _ref_beam_step(logits.clone(), scores, sizes, eos_in, max_lens, hist, step, B, beam, rep, V, ratio, pad, eos)
 
-    dev = "cuda"
     r_out = B * beam
-    z = lambda *s, dtype: torch.zeros(*s, dtype=dtype, device=dev)
-    d_logits, d_scores, d_sizes = logits.cuda(), scores.cuda(), sizes.cuda()
-    d_eos, d_max, d_hist = eos_in.to(torch.uint8).cuda(), max_lens.cuda(), hist.cuda()
-    slots_in = torch.randint(0, r_out, (rows, t_max), generator=g, dtype=torch.int32).cuda()
-    cs, ci = z(rows, beam, dtype=torch.float32), z(rows, beam, dtype=torch.int32)
-    o_scores, o_sizes, o_eos = z(r_out, dtype=torch.float32), z(r_out, dtype=torch.float32), z(r_out, dtype=torch.uint8)
-    o_hist, o_slots = z(r_out, t_max, dtype=torch.int64), z(r_out, t_max, dtype=torch.int32)
-    o_parent, o_tok, cnt = z(r_out, dtype=torch.int32), z(r_out, dtype=torch.int64), z(t_max, dtype=torch.int32)
-    a = L.BeamArgs()
-    a.B, a.beam, a.rep, a.V, a.step, a.t_max = B, beam, rep, V, step, t_max
-    a.logits, a.ld = d_logits.data_ptr(), V
-    a.scores_in, a.sizes_in, a.eos_in = d_scores.data_ptr(), d_sizes.data_ptr(), d_eos.data_ptr()
-    a.max_lens, a.hist_in, a.slots_in = d_max.data_ptr(), d_hist.data_ptr(), slots_in.data_ptr()
-    a.len_penalty_ratio, a.pad_idx, a.eos = ratio, pad, eos
-    a.cand_scores, a.cand_idx = cs.data_ptr(), ci.data_ptr()
-    a.scores_out, a.sizes_out, a.eos_out = o_scores.data_ptr(), o_sizes.data_ptr(), o_eos.data_ptr()
-    a.hist_out, a.slots_out, a.parent_out, a.tokens_out = o_hist.data_ptr(), o_slots.data_ptr(), o_parent.data_ptr(), o_tok.data_ptr()
-    a.eos_count = cnt.data_ptr()
-    O.beam_step(a)
+    slots_in = torch.randint(0, r_out, (rows, t_max), generator=g, dtype=torch.int32)
+    o = _call_beam_step(logits, scores, sizes, eos_in, max_lens, hist, slots_in, step, B, beam, rep, V, t_max, ratio, pad, eos)
+    o_hist, o_parent, o_tok, o_eos, cnt = o["hist"], o["parent"], o["tokens"], o["eos"], o["eos_count"]
+    o_scores, o_sizes, o_slots = o["scores"], o["sizes"], o["slots"]
     top, new_sizes, new_eos, new_hist, prow = exp
     assert torch.equal(o_hist.cpu()[:, :step + 1], new_hist), "token history must be bit-exact"
     assert torch.equal(o_parent.cpu().long(), prow)
@@ -158,6 +170,48 @@ def test_beam_step_matches_reference_step(cuda, beam, step):
     # slot table: ancestors' rows for positions < step, own row at `step`
     assert torch.equal(o_slots.cpu()[:, :step], slots_in.cpu()[prow, :step])
     assert torch.equal(o_slots.cpu()[:, step], torch.arange(r_out, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("beam,step", [(4, 1), (4, 3), (1, 2), (7, 2)])
+def test_beam_step_with_nan_logits_stays_in_bounds(cuda, beam, step):
+    """NaN logits (bf16 overflow, a damaged checkpoint) have no defined hypothesis, but every index the step writes
+    must stay inside its buffer (decode.hip: the 0x7fffffff sentinels of the row top-k and of the merge), and
+    sentences whose rows are finite must come out exactly as without the damage."""
+    g = torch.Generator().manual_seed(1000 + beam * 10 + step)
+    B, V, t_max, pad, eos, ratio = 6, 300, 8, 0, 4, 0.8
+    rep = 1 if step == 1 else beam
+    rows, r_out = B * rep, B * beam
+    logits = torch.randn(rows, V, generator=g) * 3
+    hist = torch.randint(6, V, (rows, t_max), generator=g)
+    hist[:, step:] = 0
+    eos_in = torch.zeros(rows, dtype=torch.bool)
+    scores = -torch.rand(rows, generator=g) * 5
+    sizes = torch.randint(1, step + 1, (rows,), generator=g).float()
+    max_lens = torch.full((B,), 9)
+    slots_in = torch.randint(0, r_out, (rows, t_max), generator=g, dtype=torch.int32)
+    clean = _call_beam_step(logits, scores, sizes, eos_in, max_lens, hist, slots_in, step, B, beam, rep, V, t_max, ratio, pad, eos)
+
+    bad = logits.clone()
+    bad[0 * rep:1 * rep] = float("nan")                        # sentence 0: every row all-NaN
+    bad[2 * rep] = float("nan")                                # sentence 2: its first row all-NaN, the others finite
+    bad[3 * rep, 5::2] = float("nan")                          # sentence 3: NaN sprinkled inside a row
+    bad_scores = scores.clone()
+    bad_scores[4 * rep] = float("nan")                         # sentence 4: NaN carried in from the previous step
+    o = _call_beam_step(bad, bad_scores, sizes, eos_in, max_lens, hist, slots_in, step, B, beam, rep, V, t_max, ratio, pad, eos)
+
+    sent = torch.arange(r_out) // beam
+    lo = sent * rep
+    assert bool(((o["cand_idx"] >= 0) & (o["cand_idx"] < V)).all()), "row candidates must be vocabulary indices"
+    assert bool(((o["parent"] >= lo) & (o["parent"] < lo + rep)).all()), "parents must be rows of the same sentence"
+    assert bool(((o["tokens"] >= 0) & (o["tokens"] < V)).all())
+    assert bool(((o["hist"][:, :step + 1] >= 0) & (o["hist"][:, :step + 1] < V)).all())
+    assert torch.equal(o["slots"][:, step], torch.arange(r_out, dtype=torch.int32))
+    assert 0 <= int(o["eos_count"][step]) <= r_out
+    # the untouched sentences (1 and 5) are bit-identical to the clean run
+    for b in (1, 5):
+        sl = slice(b * beam, (b + 1) * beam)
+        for k in ("scores", "sizes", "eos", "hist", "slots", "parent", "tokens"):
+            assert torch.equal(o[k][sl], clean[k][sl]), (b, k)
 
 
 # ------------------------------------------------------------------------------------------------ whole search

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build a second copy of the library with extra compile flags, for A/B runs inside one gpurun call:
+#   tools/build_variant.sh wt -DIMT_WT_STORES=1   ->  imagetranslate_amd/libimt_hip_wt.so   (select with IMT_LIB=<path>)
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+obj=/tmp/imt_variant_$name; mkdir -p $obj
+cd $root/imagetranslate_amd/csrc
+pids=()
+# ONLY="gemm rowops": recompile just those with the extra flags, take the other objects from the base build
+all="core gemm gemm_ln rowops attention loss optim decode batch model comm"
+for f in $all; do
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $f "; then cp $f.o $obj/$f.o; continue; fi
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable "$@" -c $f.hip -o $obj/$f.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libimt_hip_$name.so $obj/*.o -ldl
+echo built $root/imagetranslate_amd/libimt_hip_$name.so
