@@ -1,0 +1,216 @@
+"""Parity at the sizes of BASELINE.json configs[3] and configs[4] against the CPU oracle (the toy-size versions of both
+live in tests/test_gpu_model2.py; configs[1] at full size in tests/test_gpu_c1.py):
+
+  C3 captioning   frozen region features [32, 49, 2048] -> fc + location embedding -> 6-layer decoder d=512 h=8,
+                  captions [32, 32], V = 30000 (src/image_model.py:298-377 with --no-obj, src/train_captioning.py:60-80)
+  C4 MASS         monolingual src [B, 256], a span of half of each sentence masked (src/utils.py:21-66), decoder fed
+                  the span with its original positions (src/mass_seq2seq.py:11-39), 6L/6L d=512 h=8: the 256-key attention
+                  kernels (forward with two key tiles, the two-kernel backward) and the K = 2048-row dispatch are reached
+                  only here.  B = 24 of the 64 sentences (the oracle's forward + backward of 6144 encoder tokens x 12 layers
+                  takes a few seconds; the kernels' shapes per sentence are the full-size ones).
+
+fp32 compute mode: log-probs 1e-4, loss 1e-5, every gradient 3e-4 (relative to the tensor's largest entry; see
+tests/test_gpu_c1.py for why 3e-4 at this depth); bf16 mode: log-probs 4e-2, loss 2e-2, gradients 1e-1
+(up to a tenth of the tensors up to 2.5e-1 with cosine >= 0.98, see _check_grads)."""
+import random
+
+import pytest
+import torch
+
+from oracle import reference_model as R
+from tests.test_gpu_c1 import _kinds_of_step
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+DIMS = dict(enc_layer=6, dec_layer=6, embed_dim=512, intermediate_dim=2048, num_attention_heads=8)
+V = 30000
+
+
+def _make(cls_name, **kw):
+    import imagetranslate_amd.image_model as I
+    import imagetranslate_amd.mass_seq2seq as M
+    ours_cls = {"MassSeq2Seq": M.MassSeq2Seq, "ImageCaptioning": I.ImageCaptioning}[cls_name]
+    torch.manual_seed(33)
+    tp = R.SyntheticTextProcessor(V)
+    ref = getattr(R, cls_name)(tp, lang_dec=False, **DIMS, **kw).eval()
+    with torch.no_grad():  # see tests/test_gpu_c1.py: N(0, 0.02) matrices give degenerate (uniform) softmaxes
+        for k, p in ref.named_parameters():
+            if p.dim() > 1:
+                p.mul_(2.0)
+            elif k.endswith("bias"):
+                p.normal_(0.0, 0.02)
+    ours = ours_cls(tp, lang_dec=False, **DIMS, **kw)
+    missing = ours.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    return ref, ours.cuda().eval()
+
+
+def _check_grads(ours, ref, tol, min_checked, what, worst_tol=None):
+    """Every gradient tensor against the oracle's: max |a - b| / max |b| <= tol.  With ``worst_tol`` (bf16 mode) a tensor may
+    exceed ``tol`` up to ``worst_tol`` if its direction still matches (cosine >= 0.98) and at most 10 % of the tensors do:
+    the gradients of the attention query / key projections are differences of near-equal numbers under the flat attention
+    of random weights (dS = P * (dP - delta)), where 8-bit mantissas lose most of their digits."""
+    ref_params = dict(ref.named_parameters())
+    checked, loose = 0, []
+    for k, p in ours.named_parameters():
+        if k not in ref_params or ref_params[k].grad is None:
+            continue
+        g_ref = ref_params[k].grad
+        assert p.grad is not None, k
+        if float(g_ref.abs().max()) < 1e-7:  # zero in exact arithmetic (key biases): round-off on both sides
+            continue
+        g = p.grad.detach().float().cpu()
+        err = float((g - g_ref).abs().max() / g_ref.abs().max())
+        assert torch.isfinite(g).all(), k
+        if err > tol:
+            cos = float(torch.nn.functional.cosine_similarity(g.flatten(), g_ref.flatten(), dim=0))
+            assert worst_tol is not None and err <= worst_tol and cos >= 0.98, "%s grad %s: rel err %.3e (cos %.4f) > tol %.1e" % (what, k, err, cos, tol)
+            loose.append((k, err, cos))
+        checked += 1
+    assert checked >= min_checked, checked
+    assert len(loose) <= 0.1 * checked, loose
+
+
+def _check_bf16_argmax(lp, lp_ref, what):
+    """bf16 token choices: most agree with the oracle, and where one differs it is a near-tie of the ORACLE's distribution
+    (the oracle's log-prob of our choice within the bf16 log-prob tolerance of its maximum) -- random weights and random
+    features give flat distributions, where ties are common."""
+    ours_arg = lp.argmax(-1).cpu()
+    agree = float((ours_arg == lp_ref.argmax(-1)).float().mean())
+    assert agree > 0.9, "%s: bf16 argmax agreement %.3f" % (what, agree)
+    gap = lp_ref.max(-1).values - lp_ref.gather(1, ours_arg[:, None])[:, 0]
+    assert float(gap.max()) <= 4e-2 * float(lp_ref.abs().max()), "%s: a bf16 token choice is not a near-tie (gap %.4f)" % (what, float(gap.max()))
+
+
+# ------------------------------------------------------------------------------------------------ C3
+@pytest.fixture(scope="module")
+def c3(cuda):
+    ref, ours = _make("ImageCaptioning", image_feat_dim=2048, use_obj=False)
+    g = torch.Generator().manual_seed(303)
+    B, T = 32, 32
+    feats = torch.randn(B, 49, 2048, generator=g)
+    cap = torch.randint(6, V, (B, T), generator=g)
+    cap[:, 0] = 6
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    for i in range(B):
+        cap[i, lens[i] - 1] = 4
+        cap[i, lens[i]:] = 0
+    langs = torch.ones(B, dtype=torch.long)
+    kw = dict(tgt_inputs=cap, tgt_mask=cap != 0, tgt_langs=langs, batch={"images": feats})
+    ref.zero_grad()
+    lp_ref = ref(**kw, log_softmax=True)
+    loss_ref = R.SmoothedNLLLoss(ignore_index=0)(lp_ref, cap[:, 1:][(cap != 0)[:, 1:]]).mean()
+    loss_ref.backward()
+    return ref, ours, kw, lp_ref.detach(), float(loss_ref.detach())
+
+
+def test_c3_captioning_fp32_parity(c3):
+    ref, ours, kw, lp_ref, loss_ref = c3
+    ours.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        lp = ours(**kw, log_softmax=True)
+    assert lp.shape == lp_ref.shape
+    assert_close(lp, lp_ref, 1e-4, "C3 fp32 log-probs")
+    assert torch.equal(lp.argmax(-1).cpu(), lp_ref.argmax(-1)), "argmax token ids must be bit-exact"
+    ours.zero_grad()
+
+    def step():
+        loss, n = ours.loss_fused(**kw)
+        loss.backward()
+        return loss, n
+    (loss, n), kinds = _kinds_of_step(step)
+    assert n == lp_ref.shape[0]
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-5 * abs(loss_ref)
+    _check_grads(ours, ref, 3e-4, 100, "C3 fp32")   # 6 decoder layers x 26 tensors + embeddings + head + output layer
+    for k in ("image_model.fc.weight", "image_model.location_embedding.weight"):
+        assert float(dict(ours.named_parameters())[k].grad.abs().max()) > 0, k
+    assert any(k.startswith("xent_fused") for k in kinds) and any(k.startswith("attn_bwd") for k in kinds), kinds
+    assert any(k.startswith("add_rows_dropout") or k.startswith("gemm") for k in kinds), kinds
+
+
+def test_c3_captioning_bf16_parity(c3):
+    ref, ours, kw, lp_ref, loss_ref = c3
+    ours.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            lp = ours(**kw, log_softmax=True)
+        assert_close(lp, lp_ref, 4e-2, "C3 bf16 log-probs")
+        _check_bf16_argmax(lp, lp_ref, "C3")
+        ours.zero_grad()
+        loss, _ = ours.loss_fused(**kw)
+        loss.backward()
+        assert abs(float(loss.detach()) - loss_ref) <= 2e-2 * abs(loss_ref)
+        _check_grads(ours, ref, 1e-1, 100, "C3 bf16", worst_tol=2.5e-1)
+    finally:
+        ours.set_compute_dtype(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ C4
+@pytest.fixture(scope="module")
+def c4(cuda):
+    from imagetranslate_amd.utils import mass_mask
+    ref, ours = _make("MassSeq2Seq")
+    g = torch.Generator().manual_seed(404)
+    B, S = 24, 256
+    src = torch.randint(6, V, (B, S), generator=g)
+    src[:, 0] = 5
+    lens = torch.full((B,), S, dtype=torch.long)
+    lens[1::3] = torch.randint(S // 2, S, (len(lens[1::3]),), generator=g)  # a third of the sentences shorter: key masks at 256 keys
+    for i in range(B):
+        src[i, lens[i] - 1] = 4
+        src[i, lens[i]:] = 0
+    random.seed(44)
+    info = mass_mask(0.5, lens, src.clone(), R.SyntheticTextProcessor(V))
+    langs = torch.zeros(B, dtype=torch.long)
+    kw = dict(src_inputs=info["src_text"], tgt_inputs=info["to_recover"], tgt_positions=info["positions"], src_langs=langs)
+    ref.zero_grad()
+    lp_ref = ref(**kw, log_softmax=True)
+    loss_ref = R.SmoothedNLLLoss(ignore_index=0)(lp_ref, info["targets"]).mean()
+    loss_ref.backward()
+    return ref, ours, kw, info, lp_ref.detach(), float(loss_ref.detach())
+
+
+def test_c4_mass_fp32_parity(c4):
+    ref, ours, kw, info, lp_ref, loss_ref = c4
+    ours.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        lp = ours(**kw, log_softmax=True)
+    assert lp.shape == lp_ref.shape and lp.shape[0] >= 2048
+    assert_close(lp, lp_ref, 1e-4, "C4 fp32 log-probs")
+    assert torch.equal(lp.argmax(-1).cpu(), lp_ref.argmax(-1)), "argmax token ids must be bit-exact"
+    del lp
+    ours.zero_grad()
+    loss, n = ours.loss_fused(**kw)
+    loss.backward()
+    assert n == info["targets"].numel()
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-5 * abs(loss_ref)
+    _check_grads(ours, ref, 3e-4, 150, "C4 fp32")
+
+
+def test_c4_mass_bf16_parity_and_dispatch(c4):
+    ref, ours, kw, info, lp_ref, loss_ref = c4
+    ours.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            lp = ours(**kw, log_softmax=True)
+        assert_close(lp, lp_ref, 4e-2, "C4 bf16 log-probs")
+        _check_bf16_argmax(lp, lp_ref, "C4")
+        del lp
+        ours.zero_grad()
+
+        def step():
+            loss, n = ours.loss_fused(**kw)
+            loss.backward()
+            return loss, n
+        (loss, n), kinds = _kinds_of_step(step)
+        assert abs(float(loss.detach()) - loss_ref) <= 2e-2 * abs(loss_ref)
+        _check_grads(ours, ref, 1e-1, 150, "C4 bf16", worst_tol=2.5e-1)
+        # the 256-key attention path: encoder self-attention and the decoder's cross-attention take the tiled forward and the
+        # two-kernel backward (the fused single-workgroup backward is for <= 128 keys)
+        assert kinds.get("attn_bwd_dkdv_bf16", 0) >= 6 and kinds.get("attn_bwd_dq_bf16", 0) >= 6, kinds
+        assert sum(v for k, v in kinds.items() if k.startswith("gemm_ws_bf16")) >= 20, kinds
+        assert any(k.startswith("xent_fused") for k in kinds), kinds
+    finally:
+        ours.set_compute_dtype(torch.float32)
