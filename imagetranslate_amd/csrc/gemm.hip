@@ -24,6 +24,30 @@
 #include <stdlib.h>
 #include "mma.hpp"
 
+// ---- build-time tuning switches (tools/build_variant.sh builds a second library with other values for A/B runs)
+#ifndef IMT_WS_NST
+#define IMT_WS_NST 3
+#endif
+#ifndef IMT_WS_RUNAHEAD
+#define IMT_WS_RUNAHEAD 0
+#endif
+#ifndef IMT_GROUP_RUNAHEAD
+#define IMT_GROUP_RUNAHEAD 1
+#endif
+#ifndef IMT_WS_ABLATE
+#define IMT_WS_ABLATE 0
+#endif
+#ifndef IMT_WS_AHEAD
+#define IMT_WS_AHEAD true
+#endif
+#ifndef IMT_WS_ROTATE
+#define IMT_WS_ROTATE 0
+#endif
+#ifndef IMT_GROUP_NST
+#define IMT_GROUP_NST 4
+#endif
+
+
 namespace {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
@@ -119,22 +143,93 @@ struct EpiParams {
 
 // ------------------------------------------------------------------------------------------------ tile product
 template <typename T, int LAYOUT>
-IMT_DEVICE void compute_tile(f32x4 (&acc)[4][4], const char* ta, const char* tb, int wm, int wn) {
+IMT_DEVICE void load_frags(typename Frag<T>::type (&fa)[4], typename Frag<T>::type (&fb)[4], const char* ta, const char* tb, int wm,
+                           int wn, int s) {
   constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
   typedef TileGeom<T, A_KC> GA;
   typedef TileGeom<T, B_KC> GB;
-  typedef typename Frag<T>::type frag_t;
   constexpr int KSTEP = Frag<T>::KSTEP;
 #pragma unroll
-  for (int s = 0; s < GA::BK / KSTEP; ++s) {
-    frag_t fa[4], fb[4];
+  for (int i = 0; i < 4; ++i) {
+    if (A_KC) fa[i] = lds_frag_kcontig<T, GA::RB>(ta, wm + 16 * i, 4 * s);
+    else      fa[i] = KStrided<T, GA::RB>::load(ta, s * KSTEP, wm + 16 * i);
+    if (B_KC) fb[i] = lds_frag_kcontig<T, GB::RB>(tb, wn + 16 * i, 4 * s);
+    else      fb[i] = KStrided<T, GB::RB>::load(tb, s * KSTEP, wn + 16 * i);
+  }
+}
+
+// the same fragments in the order the i-major MFMA loop consumes them (acc[0][0..3] first: a[0], b[0..3], then a[1..3]): with
+// the reads of the next k-step issued one per MFMA, in-order LDS returns then never make an MFMA wait for a recent read
+template <typename T, int LAYOUT>
+IMT_DEVICE void load_frags_in_use_order(typename Frag<T>::type (&fa)[4], typename Frag<T>::type (&fb)[4], const char* ta,
+                                        const char* tb, int wm, int wn, int s) {
+  constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  typedef TileGeom<T, A_KC> GA;
+  typedef TileGeom<T, B_KC> GB;
+  constexpr int KSTEP = Frag<T>::KSTEP;
+  auto la = [&](int i) {
+    if (A_KC) fa[i] = lds_frag_kcontig<T, GA::RB>(ta, wm + 16 * i, 4 * s);
+    else      fa[i] = KStrided<T, GA::RB>::load(ta, s * KSTEP, wm + 16 * i);
+  };
+  auto lb = [&](int i) {
+    if (B_KC) fb[i] = lds_frag_kcontig<T, GB::RB>(tb, wn + 16 * i, 4 * s);
+    else      fb[i] = KStrided<T, GB::RB>::load(tb, s * KSTEP, wn + 16 * i);
+  };
+  lb(0); la(0); lb(1); lb(2); lb(3); la(1); la(2); la(3);
+}
+
+// One k-step of the software-pipelined tile product (wave-specialised kernels): the 16 fragment-pair products of the
+// fragments in (fa, fb), with the LDS reads of the NEXT k-step -- already written in the source right before this call --
+// issued one by one in the shadows of these MFMAs.  NR = LDS read instructions of a k-step for this type / layout.
+template <typename T, int LAYOUT> struct StepShape {
+  static constexpr bool A_KC = (LAYOUT != IMT_TN), B_KC = (LAYOUT == IMT_NT);
+  static constexpr int KS_READS = sizeof(T) == 2 ? 2 : 4;             // K-strided fragment: 2 ds_read_b64_tr_b16 / 4 ds_read_b32
+  static constexpr int NR = 4 * (A_KC ? 1 : KS_READS) + 4 * (B_KC ? 1 : KS_READS);
+  static constexpr int NM = 16 * (sizeof(T) == 2 ? 1 : 4);            // MFMA instructions of a k-step
+  static constexpr int PER = NM / NR > 0 ? NM / NR : 1;               // MFMAs per read slot
+};
+template <typename T, int LAYOUT, int EXTRA_MFMA = 0>
+IMT_DEVICE void mma_step_interleaved(f32x4 (&acc)[4][4], const typename Frag<T>::type (&fa)[4], const typename Frag<T>::type (&fb)[4]) {
+  typedef StepShape<T, LAYOUT> S;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (A_KC) fa[i] = lds_frag_kcontig<T, GA::RB>(ta, wm + 16 * i, 4 * s);
-      else      fa[i] = KStrided<T, GA::RB>::load(ta, s * KSTEP, wm + 16 * i);
-      if (B_KC) fb[i] = lds_frag_kcontig<T, GB::RB>(tb, wn + 16 * i, 4 * s);
-      else      fb[i] = KStrided<T, GB::RB>::load(tb, s * KSTEP, wn + 16 * i);
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (!(IMT_WS_ABLATE & 1)) mma16(acc[i][j], fb[j], fa[i]);  // C^T tile: rows <- n, cols <- m
+#pragma unroll
+  for (int k = 0; k < S::NR; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, S::PER, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one DS read
+  }
+}
+
+// AHEAD = false: fragments of a k-step are read right before its MFMAs (lowest register use; the compiler then tends to
+// reuse one register quad for consecutive fragments with a full lgkmcnt(0) between them -- 8 exposed LDS round trips per
+// tile, fine where other workgroups of the CU fill the gaps).  AHEAD = true (the wave-specialised kernels: ONE multiplying
+// wave per SIMD, nobody else to hide an LDS round trip): every fragment read of the tile is requested before the first
+// MFMA (64 VGPRs of fragments for bf16), the scheduling fence keeps the compiler from sinking them back, and the MFMAs of
+// step s wait only for the reads of steps <= s (LDS returns in order).
+template <typename T, int LAYOUT, bool AHEAD = false>
+IMT_DEVICE void compute_tile(f32x4 (&acc)[4][4], const char* ta, const char* tb, int wm, int wn) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int NS = TileGeom<T, true>::BK / Frag<T>::KSTEP;  // k-steps per tile (2)
+  if (AHEAD) {
+    frag_t fa[NS][4], fb[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) load_frags<T, LAYOUT>(fa[s], fb[s], ta, tb, wm, wn, s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma16(acc[i][j], fb[s][j], fa[s][i]);  // C^T tile: rows <- n, cols <- m
     }
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    frag_t fa[4], fb[4];
+    load_frags<T, LAYOUT>(fa, fb, ta, tb, wm, wn, s);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -579,12 +674,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict
 // tile stalls the MFMA waves of the next one.  The epilogue restages through its own 32 KiB (ring 96 KiB + 32 KiB
 // = 128 KiB: a communication workgroup of a data-parallel job can share the CU).  Producers keep their own counted vmcnt (only DMA), consumers' epilogue loads/stores
 // have theirs; the only coupling is one raw s_barrier per K tile plus the epilogue's four.
-#ifndef IMT_WS_NST
-#define IMT_WS_NST 3
-#endif
-#ifndef IMT_WS_ROTATE
-#define IMT_WS_ROTATE 0
-#endif
 constexpr int WS_NST = IMT_WS_NST;   // 96 KiB ring + 32 KiB epilogue staging = 128 KiB: leaves LDS for a co-resident communication workgroup
 constexpr int WS_THREADS = 512;
 constexpr int WS_LDS = WS_NST * STAGE_BYTES + 32768;
@@ -625,8 +714,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       }
       int tk = tq + rot;
       if (tk >= nt) tk -= nt;
-      da.issue(smem + slot * STAGE_BYTES, tk);
-      db.issue(smem + slot * STAGE_BYTES + TILE_BYTES, tk);
+      if (!(IMT_WS_ABLATE & 2)) {  // (-DIMT_WS_ABLATE=2: no DMA, the consumers multiply whatever the ring holds; 3: bare loop)
+        da.issue(smem + slot * STAGE_BYTES, tk);
+        db.issue(smem + slot * STAGE_BYTES + TILE_BYTES, tk);
+      }
       if (++tq == nt) { tq = 0; ++iq; }
     };
     int issued = 0;
@@ -634,12 +725,19 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
     for (int s0 = 0; s0 < WS_NST - 1; ++s0)
       if (issued < total) { issue_next(s0); ++issued; }
     int cur = 0, t = 0;
-    for (int q = 0; q < total; ++q) {
-      const int newer = issued - 1 - q;  // steps issued after step q (0 .. WS_NST-2)
-      if (WS_NST >= 4 && newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    const auto wait_newer = [](int newer) {  // all of this wave's DMA pieces done but those of the `newer` youngest steps
+      if (newer >= 3)      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (newer == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (IMT_WS_RUNAHEAD && total > 0) {  // run-ahead protocol: barrier q publishes step q + 1; one more barrier in front publishes step 0
+      wait_newer(issued - 1);
+      asm volatile("s_barrier" ::: "memory");
+    }
+    for (int q = 0; q < total; ++q) {
+      // steps issued after the step this barrier publishes (classic: step q; run-ahead: step q + 1)
+      wait_newer(issued - 1 - q - (IMT_WS_RUNAHEAD ? 1 : 0));
       asm volatile("s_barrier" ::: "memory");
       if (issued < total) { issue_next(cur == 0 ? WS_NST - 1 : cur - 1); ++issued; }
       cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
@@ -665,6 +763,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
     const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
     int cur = 0;
     IMT_STAMP(ep.trace, 0);
+    if (IMT_WS_RUNAHEAD && my_tiles * nt > 0) asm volatile("s_barrier" ::: "memory");  // step 0 landed (same condition as the producers' total > 0)
     for (int i = 0; i < my_tiles; ++i) {
       const int lt = imt_xcd_block(blockIdx.x + i * gridDim.x, tiles);
       const int m0 = (lt / nbx) * BM, n0 = (lt % nbx) * BN;
@@ -676,14 +775,42 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       ColSum<T> cs;
       cs.clear();
       const bool do_colsum = colsum_kernel && n0 == 0;
+#if IMT_WS_RUNAHEAD
+      // software pipeline over k-steps (see grouped_consumer_loop): barrier q has told us that K tile q + 1 has landed, so
+      // its first fragments are read while tile q is still being multiplied.  Not across output tiles: the fragments would
+      // be live through the epilogue.
+      typename Frag<T>::type f0a[4], f0b[4], f1a[4], f1b[4];
+      {
+        const char* t0 = smem + cur * STAGE_BYTES;  // first K tile of this output tile: landed (initial barrier / the previous K tile's)
+        load_frags_in_use_order<T, LAYOUT>(f0a, f0b, t0, t0 + TILE_BYTES, wm, wn, 0);
+      }
       for (int t = 0; t < nt; ++t) {
         asm volatile("s_barrier" ::: "memory");
         if (i == 0 && t == 0) IMT_STAMP(ep.trace, 1);
         const char* ta = smem + cur * STAGE_BYTES;
-        compute_tile<T, LAYOUT>(acc, ta, ta + TILE_BYTES, wm, wn);
+        load_frags_in_use_order<T, LAYOUT>(f1a, f1b, ta, ta + TILE_BYTES, wm, wn, 1);
+        mma_step_interleaved<T, LAYOUT>(acc, f0a, f0b);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nxt = (cur + 1 == WS_NST) ? 0 : cur + 1;
+        const char* tn = smem + nxt * STAGE_BYTES;  // K tile t + 1 (past the last one: read and never used)
+        load_frags_in_use_order<T, LAYOUT>(f0a, f0b, tn, tn + TILE_BYTES, wm, wn, 0);
+        mma_step_interleaved<T, LAYOUT>(acc, f1a, f1b);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
+        cur = nxt;
+      }
+#else
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_barrier" ::: "memory");
+        if (i == 0 && t == 0) IMT_STAMP(ep.trace, 1);
+        const char* ta = smem + cur * STAGE_BYTES;
+        // (-DIMT_WS_ABLATE=1: fill only.  Compile-time: a run-time branch around the product makes the compiler copy
+        // the 64 accumulator registers at every K tile, which is what such a probe then measures)
+        if (!(IMT_WS_ABLATE & 1)) compute_tile<T, LAYOUT, IMT_WS_AHEAD>(acc, ta, ta + TILE_BYTES, wm, wn);
         if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(ta);
         cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
       }
+#endif
       if (i == 0) IMT_STAMP(ep.trace, 2);
       if (i == my_tiles - 1) epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);  // producers join in
       else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
@@ -941,8 +1068,69 @@ struct GroupArgs { int count; int total_tiles; float alpha; int alpha_pad_order 
 // max()), done by partner waves on the same SIMDs it overlaps.  One raw s_barrier per K tile: producers first wait
 // (counted vmcnt) for THEIR pieces of tile t, the barrier publishes tile t to the consumers and tells the producers
 // that the consumers are done with the buffer the next DMA overwrites.
-constexpr int GROUP_NST = 4;       // 128 KiB ring: three tiles in flight
+constexpr int GROUP_NST = IMT_GROUP_NST;       // 4: 128 KiB ring, three tiles in flight
 constexpr int GROUP_THREADS = 512;
+
+// Consumer side of the grouped weight-gradient kernel: software pipeline over k-steps, across tile boundaries -- the LDS
+// reads of a k-step are issued one by one in the shadows of the previous k-step's MFMAs (one multiplying wave per SIMD:
+// nobody else hides an LDS round trip, and a burst of reads in front of the MFMAs leaves the matrix pipe idle while they
+// issue).  Barrier t tells the consumers that tile t + 1 has landed, so the first fragments of tile t + 1 are read while
+// tile t is still being multiplied.
+// CS: this workgroup also owns the bias gradient of its 128 rows of dy (column sums of the A tiles).  They ride on the
+// matrix pipe: D = ones x A-fragment is a 16 x 16 tile whose every row holds the column sums of those 16 columns, and the
+// A fragments are in registers already -- two more MFMAs per k-step and wave (the two waves that share an A strip take two
+// fragments each) instead of a second pass over the LDS tile with ~100 VALU instructions per K tile, which made these
+// workgroups the stragglers of the launch (decoder layer: 88 -> 70 us without bias gradients).
+template <typename T> IMT_DEVICE typename Frag<T>::type ones_frag();
+template <> IMT_DEVICE f32x4 ones_frag<float>() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
+template <> IMT_DEVICE bf16x8 ones_frag<bf16_t>() {
+  const bf16_t o = (bf16_t)1.0f;
+  return bf16x8{o, o, o, o, o, o, o, o};
+}
+
+template <typename T, bool CS, bool LO>
+IMT_DEVICE void grouped_consumer_loop(f32x4 (&acc)[4][4], f32x4 (&bacc)[2], const char* smem, int nt, int wm, int wn) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int MPF = sizeof(T) == 2 ? 1 : 4;  // MFMA instructions per fragment pair
+  frag_t f0a[4], f0b[4], f1a[4], f1b[4];
+  const frag_t ones = ones_frag<T>();
+  // (LO: which two of the wave's four A fragments it sums -- a template parameter, not a branch: a branch inside the loop
+  // splits the scheduling region and the compiler bunches the reads again)
+  asm volatile("s_barrier" ::: "memory");  // tile 0 landed
+  load_frags_in_use_order<T, IMT_TN>(f0a, f0b, smem, smem + TILE_BYTES, wm, wn, 0);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_barrier" ::: "memory");
+    const char* ta = smem + cur * STAGE_BYTES;
+    load_frags_in_use_order<T, IMT_TN>(f1a, f1b, ta, ta + TILE_BYTES, wm, wn, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (!(IMT_WS_ABLATE & 1)) mma16(acc[i][j], f0b[j], f0a[i]);
+    if (CS) { mma16(bacc[0], ones, f0a[LO ? 0 : 2]); mma16(bacc[1], ones, f0a[LO ? 1 : 3]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MPF, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = (cur + 1 == GROUP_NST) ? 0 : cur + 1;
+    const char* tn = smem + nxt * STAGE_BYTES;  // tile t + 1 (landed: barrier t); past the last tile: read and never used
+    load_frags_in_use_order<T, IMT_TN>(f0a, f0b, tn, tn + TILE_BYTES, wm, wn, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (!(IMT_WS_ABLATE & 1)) mma16(acc[i][j], f1b[j], f1a[i]);
+    if (CS) { mma16(bacc[0], ones, f1a[LO ? 0 : 2]); mma16(bacc[1], ones, f1a[LO ? 1 : 3]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MPF, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArgs g) {
@@ -974,6 +1162,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   ColSum<T> cs;
   cs.clear();
+  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // bias gradient (column sums of dy), IMT_GROUP_RUNAHEAD
   const bool do_colsum = P.a_colsum && n0 == 0;
 
   if (!consumer) {
@@ -985,10 +1174,34 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
     for (int s0 = 0; s0 < GROUP_NST - 1; ++s0)
       if (s0 < nt) { da.issue(smem + s0 * STAGE_BYTES, s0); db.issue(smem + s0 * STAGE_BYTES + TILE_BYTES, s0); }
     int cur = 0;
+#if IMT_GROUP_RUNAHEAD
+    // barrier t tells the consumers that tile t + 1 has landed (they read its first fragments while still multiplying
+    // tile t), and the producers that the consumers are done with tile t - 1, whose slot takes tile t + 3
+    {
+      const int newer0 = min(GROUP_NST - 2, nt - 1);
+      if (newer0 >= 3)      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (newer0 == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (newer0 == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");  // tile 0 landed
+    }
+    for (int t = 0; t < nt; ++t) {
+      const int newer = max(0, min(nt - 1, t + GROUP_NST - 2) - (t + 1));  // tiles issued after tile t + 1
+      if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      if (t + GROUP_NST - 1 < nt && !(IMT_WS_ABLATE & 2)) {
+        const int nxt = (cur == 0) ? GROUP_NST - 1 : cur - 1;
+        da.issue(smem + nxt * STAGE_BYTES, t + GROUP_NST - 1);
+        db.issue(smem + nxt * STAGE_BYTES + TILE_BYTES, t + GROUP_NST - 1);
+      }
+      cur = (cur + 1 == GROUP_NST) ? 0 : cur + 1;
+    }
+#else
     for (int t = 0; t < nt; ++t) {
       const int newer = min(GROUP_NST - 2, nt - 1 - t);
-      if (WS_NST >= 4 && newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (newer >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (newer >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
@@ -999,9 +1212,15 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
       }
       cur = (cur + 1 == GROUP_NST) ? 0 : cur + 1;
     }
+#endif
   } else {
     // ------------------------------------------------------------ consumer waves
     int cur = 0;
+#if IMT_GROUP_RUNAHEAD
+    if (!do_colsum)   grouped_consumer_loop<T, false, false>(acc, bacc, smem, nt, wm, wn);
+    else if (wn == 0) grouped_consumer_loop<T, true, true>(acc, bacc, smem, nt, wm, wn);
+    else              grouped_consumer_loop<T, true, false>(acc, bacc, smem, nt, wm, wn);
+#else
     for (int t = 0; t < nt; ++t) {
       asm volatile("s_barrier" ::: "memory");
       const char* ta = smem + cur * STAGE_BYTES;
@@ -1009,6 +1228,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
       if (do_colsum) cs.add_tile(ta);
       cur = (cur + 1 == GROUP_NST) ? 0 : cur + 1;
     }
+#endif
   }
   EpiParams ep;
   ep.C = P.C; ep.ldc = P.ldc; ep.c_f32 = 1; ep.accumulate = 1;
@@ -1018,7 +1238,16 @@ __global__ __launch_bounds__(GROUP_THREADS) void gemm_grouped_tn_kernel(GroupArg
   // one tile per workgroup: the epilogue is fully exposed, so all 8 waves share it (the producers have nothing left to do)
   if (consumer) epilogue<T, 512, true>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
   else epilogue<T, 512, false>(acc, smem, m0, n0, wm, wn, M, N, ep, g.alpha);
+#if IMT_GROUP_RUNAHEAD
+  if (do_colsum && consumer && (threadIdx.x & 63) < 16) {
+    // every row of the 16 x 16 tile holds the same sums: lanes 0-15 (row group 0) publish element 0; one contributor per column
+    const int mb = m0 + wm + ((wn == 0) ? 0 : 32) + (threadIdx.x & 15);
+    if (mb < M)      atomicAdd(P.a_colsum + mb, bacc[0][0] * g.alpha);
+    if (mb + 16 < M) atomicAdd(P.a_colsum + mb + 16, bacc[1][0] * g.alpha);
+  }
+#else
   if (do_colsum) cs.flush(smem, P.a_colsum, m0, M, g.alpha, consumer);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host side
