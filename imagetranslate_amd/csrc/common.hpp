@@ -203,7 +203,9 @@ IMT_DEVICE float wave_max(float v) {
 IMT_DEVICE void erf_and_gauss(float z, float& erf_v, float& gauss) {
   const float x = fabsf(z) * 0.70710678118654752440f;
   const float e = __expf(-x * x);
-  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  // v_rcp_f32 (1 ulp) -- __frcp_rn / a plain division expand to the 11-instruction IEEE sequence (div_scale, rcp, five FMAs,
+  // div_fmas, div_fixup), 40 % of this function, in epilogues that are VALU-bound (12 us of a 28-us FFN-up GEMM)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -211,6 +213,44 @@ IMT_DEVICE void erf_and_gauss(float z, float& erf_v, float& gauss) {
   const float y = 1.0f - p * t * e;
   erf_v = copysignf(y, z);
   gauss = e;
+}
+// Four elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32: two lanes' worth per issue slot): the GELU and
+// GELU' epilogues of the FFN GEMMs run no MFMA beside this math and are bound by VALU issue (64 K elements per 256 x 256
+// tile); ~13 issue slots per element against ~19 for the scalar form.  Same operations in the same order as the scalar
+// functions below (which serve ragged tails).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+IMT_DEVICE f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+IMT_DEVICE void erf_and_gauss2(f32x2 z, f32x2& erf_v, f32x2& gauss) {
+  const f32x2 x = __builtin_elementwise_abs(z) * 0.70710678118654752440f;
+  const f32x2 a = x * x * -1.4426950408889634f;  // exp(-x^2) = exp2(-x^2 log2 e)
+  f32x2 e, t;
+  e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
+  const f32x2 d = pk_fma(x, f32x2{0.3275911f, 0.3275911f}, f32x2{1.f, 1.f});
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  // -(a1 t + ... + a5 t^5) / t with the signs folded into the coefficients
+  f32x2 p = pk_fma(t, f32x2{-1.061405429f, -1.061405429f}, f32x2{1.453152027f, 1.453152027f});
+  p = pk_fma(p, t, f32x2{-1.421413741f, -1.421413741f});
+  p = pk_fma(p, t, f32x2{0.284496736f, 0.284496736f});
+  p = pk_fma(p, t, f32x2{-0.254829592f, -0.254829592f});
+  const f32x2 y = pk_fma(p * t, e, f32x2{1.f, 1.f});
+  erf_v.x = copysignf(y.x, z.x); erf_v.y = copysignf(y.y, z.y);
+  gauss = e;
+}
+IMT_DEVICE f32x4 gelu_erf4(f32x4 v) {
+  f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]}, e0, g0, e1, g1;
+  erf_and_gauss2(lo, e0, g0);
+  erf_and_gauss2(hi, e1, g1);
+  lo = lo * 0.5f * (e0 + 1.0f);
+  hi = hi * 0.5f * (e1 + 1.0f);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+IMT_DEVICE f32x4 gelu_erf_grad4(f32x4 z) {
+  f32x2 lo = {z[0], z[1]}, hi = {z[2], z[3]}, e0, g0, e1, g1;
+  erf_and_gauss2(lo, e0, g0);
+  erf_and_gauss2(hi, e1, g1);
+  lo = pk_fma(lo * 0.39894228040143267794f, g0, (e0 + 1.0f) * 0.5f);
+  hi = pk_fma(hi * 0.39894228040143267794f, g1, (e1 + 1.0f) * 0.5f);
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 IMT_DEVICE float gelu_erf(float z) {
   float er, ga;

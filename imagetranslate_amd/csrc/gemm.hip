@@ -363,13 +363,11 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
       f32x4 v = *reinterpret_cast<const f32x4*>(smem + epi_off(row, c4)) + bv;
       if (KIND == EM_GELU) {
         if (live) Vec4<T>::store(aux + m * ep.ldaux + n, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        v = gelu_erf4(v);
       }
       if (KIND == EM_DGELU) {
         const f32x4 z = Vec4<T>::cvt(pr[gq]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
+        v *= gelu_erf_grad4(z);
       }
       if (KIND == EM_DROP_RESID) {
         if ((N & 3) == 0) {  // n % 4 == 0: the lane's four elements are one block of the dropout generator
@@ -413,12 +411,10 @@ IMT_DEVICE void epilogue_general(const f32x4 (*acc)[4], char* smem, int m0, int 
         if (bias) v += Vec4<T>::load(bias + n);
         if (ep.aux_mode == IMT_AUX_GELU_FWD) {
           Vec4<T>::store(aux + (int64_t)m * ep.ldaux + n, v);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          v = gelu_erf4(v);
         } else if (ep.aux_mode == IMT_AUX_DGELU) {
           const f32x4 z = Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
+          v *= gelu_erf_grad4(z);
         }
         if (ep.drop_thresh) {
 #pragma unroll
@@ -908,12 +904,10 @@ IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, int
       f32x4 v = acc[i][j] * alpha + bv[j];
       if (AUX == IMT_AUX_GELU_FWD) {
         if (live) Vec4<T>::store(aux + m * ep.ldaux + n, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        v = gelu_erf4(v);
       } else if (AUX == IMT_AUX_DGELU) {
         const f32x4 z = Vec4<T>::cvt(zr[i & 1][j]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(z[e]);
+        v *= gelu_erf_grad4(z);
       }
       if (live) {
         if (C_F32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
