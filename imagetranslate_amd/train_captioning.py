@@ -18,7 +18,7 @@ from .param_store import store_of
 from .seq2seq import Seq2Seq
 from .seq_gen import BeamDecoder, get_outputs_until_eos
 from .textprocessor import TextProcessor
-from .train_image_mt import ImageMTTrainer, init_distributed, reject_off_path
+from .train_image_mt import ImageMTTrainer, LossMeter, init_distributed, reject_off_path
 from .utils import build_optimizer
 
 
@@ -41,7 +41,7 @@ class ImageCaptionTrainer(ImageMTTrainer):
         loss.backward()
         scale = self.sync.finish() if self.sync is not None else 1.0
         self._finish_micro_step(loss, accum, scale)
-        return float(loss.detach()), int(ntokens)
+        return loss.detach(), int(ntokens)
 
     @torch.no_grad()
     def caption_dev_loss(self, img_dev_data):
@@ -83,7 +83,7 @@ class ImageCaptionTrainer(ImageMTTrainer):
             order = order + order[:(-len(order)) % self.world_size]
         order = order[self.rank::self.world_size]
         self.epoch += 1
-        tokens, cur_loss, t0 = 0, 0.0, datetime.datetime.now()
+        meter, t0 = LossMeter(), datetime.datetime.now()
         for kind, i in order:
             if step >= max_step:
                 break
@@ -101,13 +101,13 @@ class ImageCaptionTrainer(ImageMTTrainer):
             if n == 0:
                 continue
             step += 1
-            tokens += n
-            cur_loss += loss * n
-            if step % log_every == 0 and self.rank == 0:
-                secs = (datetime.datetime.now() - t0).total_seconds()
-                print(datetime.datetime.now(), "Epoch Step: %d Loss: %f Tokens per Sec: %f " % (step, cur_loss / max(tokens, 1), tokens / max(secs, 1e-9)),
-                      flush=True)
-                tokens, cur_loss, t0 = 0, 0.0, datetime.datetime.now()
+            meter.add(loss, n)
+            if step % log_every == 0:
+                mean, tokens = meter.read()
+                if self.rank == 0:
+                    secs = (datetime.datetime.now() - t0).total_seconds()
+                    print(datetime.datetime.now(), "Epoch Step: %d Loss: %f Tokens per Sec: %f " % (step, mean, tokens / max(secs, 1e-9)), flush=True)
+                t0 = datetime.datetime.now()
             if step % eval_every == 0:
                 self._validate(img_dev_data, mt_dev_data, save_path)
         return step

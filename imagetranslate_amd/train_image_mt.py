@@ -49,7 +49,7 @@ class ImageMTTrainer:
         self.micro_step += 1
         loss, ntokens = train_step(self.model, self.optimizer, batch, sync=self.sync, clip=self.clip,
                                    update=(self.micro_step % max(1, accum) == 0), loss_weight=loss_weight)
-        return float(loss.detach()), int(ntokens)
+        return loss.detach(), int(ntokens)  # the loss stays on the device: reading it here would stall the host every step
 
     # one MASS batch (src/train_image_mt.py:186-236): mask a span, recover it with its original positions
     def mass_step(self, batch, accum: int = 1):
@@ -64,7 +64,7 @@ class ImageMTTrainer:
         loss.backward()
         scale = self.sync.finish() if self.sync is not None else 1.0
         self._finish_micro_step(loss, accum, scale)
-        return float(loss.detach()), int(ntokens)
+        return loss.detach(), int(ntokens)
 
     @torch.no_grad()
     def dev_loss(self, dev_data):
@@ -94,7 +94,7 @@ class ImageMTTrainer:
                     save_path: str = None, log_every: int = 50, eval_every: int = 500, accum: int = 1):
         order = self.epoch_order(len(mt_data or []), len(mass_data or []))
         self.epoch += 1
-        tokens, total_loss, t0 = 0, 0.0, datetime.datetime.now()
+        meter, t0 = LossMeter(), datetime.datetime.now()
         for kind, i in order:
             if step >= max_step:
                 break
@@ -107,13 +107,14 @@ class ImageMTTrainer:
                 self.optimizer.zero_grad()
                 continue
             step += 1
-            tokens += n
-            total_loss += loss * n
-            if step % log_every == 0 and self.rank == 0:
-                secs = (datetime.datetime.now() - t0).total_seconds()
-                print(datetime.datetime.now(), "step", step, "loss %.4f" % (total_loss / max(tokens, 1)), "tokens/s %.0f" % (tokens / max(secs, 1e-9)),
-                      "lr %.2e" % self.optimizer.param_groups[0]["lr"], flush=True)
-                tokens, total_loss, t0 = 0, 0.0, datetime.datetime.now()
+            meter.add(loss, n)
+            if step % log_every == 0:
+                mean, tokens = meter.read()  # the only host read of the losses: once per log_every steps, on every rank
+                if self.rank == 0:
+                    secs = (datetime.datetime.now() - t0).total_seconds()
+                    print(datetime.datetime.now(), "step", step, "loss %.4f" % mean, "tokens/s %.0f" % (tokens / max(secs, 1e-9)),
+                          "lr %.2e" % self.optimizer.param_groups[0]["lr"], flush=True)
+                t0 = datetime.datetime.now()
             if dev_data is not None and step % eval_every == 0:
                 self.validate_and_save(dev_data, save_path)
         return step
@@ -126,6 +127,25 @@ class ImageMTTrainer:
                 self.model.save(save_path)
         self.best_loss = min(self.best_loss, dl)
         return dl
+
+
+class LossMeter:
+    """Token-weighted running mean of per-step losses that stay on the device until ``read()`` (the reference reads
+    ``loss.item()`` every step, src/train_image_mt.py:284: a host stall per step that lets the GPU idle while the host
+    prepares the next batch)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, loss, n: int):
+        if n:
+            self.items.append((loss, int(n)))
+
+    def read(self):
+        tokens = sum(n for _, n in self.items)
+        total = sum(float(l) * n for l, n in self.items)
+        self.items = []
+        return total / max(tokens, 1), tokens
 
 
 def get_option_parser():

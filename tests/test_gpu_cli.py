@@ -94,7 +94,7 @@ def test_trainer_mass_steps_on_device_batches(cuda):
             loss, n = trainer.mass_step(b)
             assert torch.equal(b["src_texts"], before), "the dataset's tensors are not modified"
             assert n == int((b["pad_idx"] // 2).sum())
-            losses.append(loss)
+            losses.append(float(loss))
     k = len(data)
     assert sum(losses[-k:]) / k < 0.75 * sum(losses[:k]) / k, (losses[:k], losses[-k:])
 
