@@ -33,6 +33,11 @@ class GemmArgs(Structure):
         ("alpha_dev", c_void_p),
         ("a_colsum", c_void_p),
         ("force_general", c_int32), ("force_pipeline", c_int32),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
+        ("ln_out", c_void_p), ("ld_ln", c_int64),
+        ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
+        ("ln_tickets", c_void_p),
+        ("ln_eps", c_float), ("reserved_ln", c_int32),
     ]
 
 

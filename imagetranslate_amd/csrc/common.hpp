@@ -41,6 +41,7 @@ void imt_set_error(const char* fmt, ...);
 
 static inline int imt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+bool imt_gemm_ln_ticket_enabled();  // gemm.hip: built with -DIMT_LN_TICKET=1 (imt_gemm's ln_out can normalise in-launch)
 // ---------------------------------------------------------------- optional launch profiler (core.hip)
 bool imt_prof_enabled();
 const char* imt_prof_intern(const char* kind, int M, int N, int K);
@@ -156,6 +157,14 @@ template <> struct Vec4<float> {
   typedef f32x4 type;
   static IMT_DEVICE f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static IMT_DEVICE void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  // write-through (sc1) store: the bytes leave the XCD's L2 as the store completes -- for data that another workgroup of the
+  // SAME launch reads (imt_gemm's in-launch LayerNorm); two 8-byte stores (the parity mode, not the fast path)
+  static IMT_DEVICE void store_wt(float* p, f32x4 v) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   static IMT_DEVICE type load_raw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }  // no conversion: the
   static IMT_DEVICE f32x4 cvt(type v) { return v; }                                                // load stays in flight
 };
@@ -174,6 +183,11 @@ template <> struct Vec4<bf16_t> {
 #else
     *reinterpret_cast<bf16x4*>(p) = r;
 #endif
+  }
+  static IMT_DEVICE void store_wt(bf16_t* p, f32x4 v) {  // global_store_dwordx2 ... sc1
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   }
   static IMT_DEVICE type load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
   static IMT_DEVICE f32x4 cvt(type v) {

@@ -28,6 +28,13 @@
 #ifndef IMT_WS_NST
 #define IMT_WS_NST 3
 #endif
+#ifndef IMT_LN_TICKET
+#define IMT_LN_TICKET 0  // 1: imt_gemm's ln_out normalises finished row blocks inside the persistent kernel's launch (row-block
+                         // tickets, ln_rowblock_tail).  Measured on C1: the tail costs 18 us per
+                         // launch against 8.9 us for the LayerNorm launch it replaces, and the code alone, switched off at
+                         // run time, slows every persistent launch (+0.38 ms per step) -- so it is compiled out and ln_out
+                         // takes a second launch
+#endif
 #ifndef IMT_WS_RUNAHEAD
 #define IMT_WS_RUNAHEAD 0
 #endif
@@ -139,6 +146,9 @@ struct EpiParams {
   int dbg;          // tuning only (tools/gemm_shapes.py): bit0 skip the tile products, bit1 skip the in-loop DMA
   unsigned long long* trace;  // tuning only (IMT_TRACE=gemm_ws | gemm_xl): per-workgroup phase time stamps
   int64_t slab_elems;         // 256-tile kernel, split-K slab mode: C of K split y = C + y * slab_elems (fp32 slabs)
+  // in-launch LayerNorm of finished row blocks (persistent kernel, one tile per workgroup; ln_rowblock_tail)
+  const void* ln_gamma = nullptr; const void* ln_beta = nullptr; void* ln_out = nullptr; int64_t ld_ln = 0;
+  float* ln_mean = nullptr; float* ln_rstd = nullptr; int* ln_tickets = nullptr; float ln_eps = 0.f;
 };
 
 // ------------------------------------------------------------------------------------------------ tile product
@@ -382,8 +392,13 @@ IMT_DEVICE void epilogue_fast(const f32x4 (*acc)[4], char* smem, int m0, int n0,
       if (KIND == EM_F32_ACC) v += pc[gq];
       if (live) {
         // (non-temporal stores here, to leave less dirty data for the end-of-kernel write-back: no measurable change)
-        if (C32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
-        else     Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+        if (IMT_LN_TICKET && ep.ln_out) {  // read by another workgroup of this launch: write-through (uniform branch)
+          if (C32) Vec4<float>::store_wt(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+          else     Vec4<T>::store_wt(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+        } else {
+          if (C32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+          else     Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
+        }
       }
     }
   }
@@ -425,11 +440,11 @@ IMT_DEVICE void epilogue_general(const f32x4 (*acc)[4], char* smem, int m0, int 
         if (ep.c_f32) {
           float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
           if (ep.accumulate) v += Vec4<float>::load(c);
-          Vec4<float>::store(c, v);
+          if (IMT_LN_TICKET && ep.ln_out) Vec4<float>::store_wt(c, v); else Vec4<float>::store(c, v);
         } else {
           T* c = reinterpret_cast<T*>(ep.C) + (int64_t)m * ep.ldc + n;
           if (ep.accumulate) v += Vec4<T>::load(c);
-          Vec4<T>::store(c, v);
+          if (IMT_LN_TICKET && ep.ln_out) Vec4<T>::store_wt(c, v); else Vec4<T>::store(c, v);
         }
         continue;
       }
@@ -663,6 +678,108 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(const T* __restrict
 }
 
 
+// ------------------------------------------------------------------------------------------------ in-launch LayerNorm
+// LayerNorm(dropout(dense(x)) + input) without a second launch (src/bert_seq2seq.py:84-90,139-143).  A row needs all N
+// columns, i.e. the nbx column tiles of its 128-row block, which different workgroups compute.  No workgroup waits for
+// another: every workgroup stores its C tile write-through (sc1), drains its stores, and one lane takes a ticket of the row
+// block with an agent-scope atomic add; the workgroup whose ticket is the last one (nbx - 1) knows that all tiles of the
+// block are in memory and normalises the block's rows, reading C around its L1 / L2 (sc1 loads: the other tiles were
+// written by other CUs).  This is the "last arriver" hand-off of MI355X_MICROARCH.md (section Workgroup dispatch ...:
+// every store of the handed-off bytes sc1 and drained by its wave before the workgroup's one atomic add; every load of them
+// an sc1 buffer load to registers issued after the add has returned and a workgroup barrier).  The ticket returns to zero
+// for the next launch.  All WS_THREADS threads of the workgroup call this (barriers inside).
+// the rows of one finished block: each wave takes 16 of the 128 rows, eight at a time with all their loads in flight
+// (a row is one dependent load -> reduce -> store chain: taken one by one, sixteen memory round trips per wave)
+template <typename T, int NCH>
+IMT_DEVICE void ln_finished_rows(const EpiParams& ep, int m0, int rows, int M, int N) {
+  constexpr int EPL = 16 / sizeof(T);  // elements per lane and chunk (one 16-byte load)
+  constexpr int CW = 64 * EPL;         // columns per chunk
+  constexpr int RB = 8;                // rows in flight per wave
+  typedef typename Frag<T>::type vec_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // one descriptor over the whole C view; offsets stay below 2^31 (host-checked)
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(ep.C, 0, (int)(((int64_t)(M - 1) * ep.ldc + N) * sizeof(T)), 0x00020000);
+  float g[NCH][EPL], b[NCH][EPL];
+  int col[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    col[i] = min(lane * EPL + i * CW, N - EPL);  // clamped: loads unconditional, masked at use
+    const vec_t gv = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(ep.ln_gamma) + col[i]);
+    const vec_t bv = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(ep.ln_beta) + col[i]);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { g[i][e] = (float)gv[e]; b[i][e] = (float)bv[e]; }
+  }
+  for (int r0 = wave * 16; r0 < rows; r0 += 16 * 8) {  // (128 rows, 8 waves: one trip)
+#pragma unroll
+    for (int h = 0; h < 16; h += RB) {
+      u32x4 raw[RB][NCH];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int64_t m = m0 + min(r0 + h + k, rows - 1);  // clamped row: read, not used
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          raw[k][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, (int)((m * ep.ldc + col[i]) * sizeof(T)), 0, 16 /* sc1 */));
+      }
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + h + k;
+        const int64_t m = m0 + r;
+        float v[NCH][EPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const vec_t x = __builtin_bit_cast(vec_t, raw[k][i]);
+          const bool live = lane * EPL + i * CW < N;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) { v[i][e] = (float)x[e]; if (live) s += v[i][e]; }
+        }
+        const float mean = wave_sum(s) / (float)N;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (lane * EPL + i * CW < N) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { const float t = v[i][e] - mean; q += t * t; }
+          }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + ep.ln_eps);
+        if (r < rows) {
+          if (lane == 0) {
+            if (ep.ln_mean) ep.ln_mean[m] = mean;
+            if (ep.ln_rstd) ep.ln_rstd[m] = rstd;
+          }
+          T* yr = reinterpret_cast<T*>(ep.ln_out) + m * ep.ld_ln;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const int c = lane * EPL + i * CW;
+            if (c < N) {
+              vec_t o;
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) o[e] = from_f32<T>((v[i][e] - mean) * rstd * g[i][e] + b[i][e]);
+              *reinterpret_cast<vec_t*>(yr + c) = o;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+IMT_DEVICE void ln_rowblock_tail(const EpiParams& ep, char* lds, int m0, int row_block, int nbx, int M, int N) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's C stores have completed (written through)
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(lds);
+  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ep.ln_tickets + row_block, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*flag != nbx - 1) return;  // uniform
+  if (threadIdx.x == 0) __hip_atomic_store(ep.ln_tickets + row_block, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int rows = min(BM, M - m0);
+  const int nch = (N + 1024 / (int)sizeof(T) - 1) / (1024 / (int)sizeof(T));  // 16-byte loads: 512 bf16 / 256 fp32 columns per chunk
+  if (nch <= 1)      ln_finished_rows<T, 1>(ep, m0, rows, M, N);
+  else if (nch == 2) ln_finished_rows<T, 2>(ep, m0, rows, M, N);
+  else               ln_finished_rows<T, 4>(ep, m0, rows, M, N);  // N <= 1024 (host-checked)
+}
+
 // ------------------------------------------------------------------------------------------------ persistent wave-specialised kernel
 // The main GEMM loop of the path when K is a whole number of tiles: 512 threads, waves 0-3 multiply (64x64 each),
 // waves 4-7 stream the operand tiles by LDS-DMA into a 3-stage ring and run AHEAD ACROSS OUTPUT TILES (one workgroup
@@ -746,6 +863,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
           const f32x4 none[4][4] = {};
           const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
           epilogue<T, 512, false>(none, epi, (lt / nbx) * BM, (lt % nbx) * BN, -1, 0, M, N, ep, alpha);
+          if (IMT_LN_TICKET && ep.ln_out) ln_rowblock_tail<T>(ep, epi, (lt / nbx) * BM, lt / nbx, nbx, M, N);  // (host: one tile per workgroup)
         } else {
           // the consumers' epilogue: 2 passes x 2 barriers
           asm volatile("s_barrier\n\ts_barrier\n\ts_barrier\n\ts_barrier" ::: "memory");
@@ -808,8 +926,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       }
 #endif
       if (i == 0) IMT_STAMP(ep.trace, 2);
-      if (i == my_tiles - 1) epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);  // producers join in
-      else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
+      if (i == my_tiles - 1) {
+        epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);  // producers join in
+        if (IMT_LN_TICKET && ep.ln_out) ln_rowblock_tail<T>(ep, epi, m0, lt / nbx, nbx, M, N);
+      } else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
       if (i == 0) IMT_STAMP(ep.trace, 3);
       if (i == my_tiles - 1) IMT_STAMP(ep.trace, 4);
       if (colsum_kernel) cs.flush(epi, ep.a_colsum, m0, M, alpha, do_colsum);
@@ -1398,6 +1518,7 @@ static bool share_cus_policy() {
   if (env) return atoi(env) != 0 || env[0] == '\0';
   return g_share_cus != 0;
 }
+bool imt_gemm_ln_ticket_enabled() { return IMT_LN_TICKET != 0; }
 extern "C" int imt_set_gemm_share_cus(int share_cus) {
   const int prev = g_share_cus;
   g_share_cus = share_cus ? 1 : 0;
@@ -1462,6 +1583,7 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     tail.A = reinterpret_cast<const char*>(a->A) + a_off * es;
     tail.B = reinterpret_cast<const char*>(a->B) + b_off * es;
     body.K = kb; body.accumulate = 1; body.bias = nullptr; body.resid = nullptr;
+    tail.ln_out = nullptr;  // the LayerNorm (if any) follows the complete product
     const int rc = imt_gemm(&tail, stream);
     if (rc != IMT_OK) return rc;
     return imt_gemm(&body, stream);
@@ -1512,8 +1634,26 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   ep.dbg = dbg;
   ep.trace = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->dtype == IMT_F32) return dispatch<float>(a, ep, splits, kps, variant, st);
-  return dispatch<bf16_t>(a, ep, splits, kps, variant, st);
+  // LayerNorm of the finished rows: in-launch (ln_rowblock_tail) when this is a one-tile-per-workgroup launch of the
+  // persistent kernel over whole 128-column tiles; otherwise a LayerNorm launch behind the GEMM
+  bool ln_in_launch = false;
+  if (a->ln_out) {
+    IMT_CHECK_ARG(a->ln_gamma && a->ln_beta, "imt_gemm: ln_out needs ln_gamma and ln_beta");
+    IMT_CHECK_ARG(a->c_dtype == a->dtype && splits == 1 && !a->accumulate, "imt_gemm: ln_out needs C of the compute type, no split-K, no accumulate");
+    static const bool no_ticket = getenv("IMT_GEMM_LN_TICKET") && atoi(getenv("IMT_GEMM_LN_TICKET")) == 0;  // tuning / tests
+    const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
+    ln_in_launch = IMT_LN_TICKET && !no_ticket && variant == 5 && tiles <= 256 && a->N % BN == 0 && a->N <= 1024 && a->ln_tickets != nullptr &&
+                   ((int64_t)(a->M - 1) * a->ldc + a->N) * es < (1ll << 31);
+    if (ln_in_launch) {
+      ep.ln_gamma = a->ln_gamma; ep.ln_beta = a->ln_beta; ep.ln_out = a->ln_out; ep.ld_ln = a->ld_ln;
+      ep.ln_mean = a->ln_mean; ep.ln_rstd = a->ln_rstd; ep.ln_tickets = a->ln_tickets; ep.ln_eps = a->ln_eps;
+    } else {
+      IMT_CHECK_ARG(a->ldc == a->N && a->ld_ln == a->N, "imt_gemm: ln_out behind a GEMM that cannot normalise in-launch needs contiguous C and ln_out");
+    }
+  }
+  const int rc = (a->dtype == IMT_F32) ? dispatch<float>(a, ep, splits, kps, variant, st) : dispatch<bf16_t>(a, ep, splits, kps, variant, st);
+  if (rc != IMT_OK || !a->ln_out || ln_in_launch) return rc;
+  return imt_layernorm_fwd(a->dtype, a->C, a->ln_gamma, a->ln_beta, a->ln_out, a->ln_mean, a->ln_rstd, a->M, a->N, a->ln_eps, 0.f, 0, stream);
 }
 
 extern "C" int imt_gemm_grouped_tn(const imt_gemm_args* list, int count, void* stream) {

@@ -61,6 +61,8 @@ struct StackWs {
   float* ln_partial;                 // [3 * layers + 1][IMT_LN_BWD_WS_FLOATS(d)]: per-XCD dgamma|dbeta partial sums of every
                                      // LayerNorm site (layer l: 3l = FFN, 3l+1 = cross, 3l+2 = self; last = embeddings)
   float* ln_site(int site, int d) const { return ln_partial + (int64_t)site * IMT_LN_BWD_WS_FLOATS(d); }
+  int32_t* ln_tickets;               // [ceil(N / 128)] row-block tickets of imt_gemm's in-launch LayerNorm (zero between launches)
+  int64_t ln_ticket_bytes;
   int64_t bytes;
 };
 
@@ -130,11 +132,14 @@ void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, 
   w.d_emb = c.take(N * d * es);
   w.delta = (float*)c.take((int64_t)B * m->heads * T * 4);
   w.ln_partial = (float*)c.take((int64_t)(3 * m->n_layers + 1) * IMT_LN_BWD_WS_FLOATS(d) * 4);
+  w.ln_ticket_bytes = ((N + 127) / 128 + 1) * 4;
+  w.ln_tickets = (int32_t*)c.take(w.ln_ticket_bytes);
   w.bytes = c.off;
 }
 
 struct Ctx {
   const imt_stack_desc* m; hipStream_t st; int dtype; int64_t es;
+  int32_t* ln_tickets = nullptr;  // zeroed row-block tickets (imt_stack_forward); null: dense + LayerNorm as two launches
   const char* P(int64_t off) const { return reinterpret_cast<const char*>(m->params) + off * es; }
   float* G(int64_t off) const { return m->grads + off; }
 };
@@ -183,8 +188,18 @@ int dense_resid_ln(const Ctx& c, const void* x, int64_t ldx, int M, int K, int64
   if (fuse_dense_ln(c, M, N, K))
     return imt_gemm_bias_residual_ln(c.dtype, x, ldx, c.P(w_off), K, b_off >= 0 ? c.P(b_off) : nullptr, resid, N, c.P(g_off), c.P(beta_off),
                                      pre_ln, out, N, mean, rstd, M, N, K, c.m->ln_eps, drop_p, seed, c.st);
-  RC(linear_fwd(c, x, ldx, M, K, w_off, b_off, N, pre_ln, N, resid, N, nullptr, IMT_AUX_NONE, drop_p, seed));
-  return imt_layernorm_fwd(c.dtype, pre_ln, c.P(g_off), c.P(beta_off), out, mean, rstd, M, N, c.m->ln_eps, 0.f, 0, c.st);
+  // imt_gemm with the LayerNorm of the finished rows: in the GEMM's own launch where it is a one-tile-per-workgroup launch
+  // of the persistent kernel (the C1 shapes: the last column tile of a 128-row block normalises it), else a second launch
+  imt_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = c.dtype; a.layout = IMT_NT; a.M = M; a.N = N; a.K = K;
+  a.A = x; a.lda = ldx; a.B = c.P(w_off); a.ldb = K; a.C = pre_ln; a.ldc = N; a.c_dtype = c.dtype;
+  a.bias = b_off >= 0 ? c.P(b_off) : nullptr;
+  a.resid = resid; a.ldr = N; a.aux_mode = IMT_AUX_NONE; a.split_k = 1; a.alpha = 1.f;
+  a.dropout_p = drop_p; a.dropout_seed = seed;
+  a.ln_gamma = c.P(g_off); a.ln_beta = c.P(beta_off); a.ln_out = out; a.ld_ln = N; a.ln_mean = mean; a.ln_rstd = rstd;
+  a.ln_eps = c.m->ln_eps; a.ln_tickets = c.ln_tickets;
+  return imt_gemm(&a, c.st);
 }
 
 // Weight-gradient GEMMs of one layer are collected here and issued as ONE grouped launch at the end of the layer's
@@ -380,6 +395,12 @@ extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io
   const bool training = io->training != 0;
   const uint64_t seed = io->dropout_seed;
   void* x0 = (m->n_layers == 0) ? io->out : w.x0;
+  // row-block tickets of the in-launch LayerNorm: zero on entry of every launch that uses them (each leaves them zero;
+  // the workspace itself arrives uninitialised)
+  if (m->n_layers > 0 && imt_gemm_ln_ticket_enabled()) {
+    if (hipMemsetAsync(w.ln_tickets, 0, w.ln_ticket_bytes, c.st) != hipSuccess) { imt_set_error("stack forward: memset of the LayerNorm tickets failed"); return IMT_ERR_LAUNCH; }
+    c.ln_tickets = w.ln_tickets;
+  }
   // parameters still being written by an optimizer step on another stream: wait site by site (imt_stack_io.wait_events)
   auto wait_site = [&](int k) {
     if (io->wait_events && k < io->n_wait_events && io->wait_events[k])

@@ -61,7 +61,7 @@ def _rowmajor(t):
 
 def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=None, aux_mode=IMT_AUX_NONE,
          accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0, alpha_dev=None, a_colsum=None,
-         force_general=False, force_pipeline=False, _launch=True):
+         force_general=False, force_pipeline=False, ln=None, _launch=True):
     """C = epilogue(op(A) op(B)); see include/imt_hip.h:imt_gemm."""
     _req_cuda(A, B, out, bias, resid, aux)
     if layout == IMT_NT:
@@ -90,6 +90,14 @@ def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=N
     a.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None
     a.force_general = int(force_general)
     a.force_pipeline = int(force_pipeline)
+    if ln is not None:
+        # ln = dict(gamma, beta, out, mean, rstd, tickets (int32, zero), eps): LayerNorm of the rows of `out` in the same call
+        _req_cuda(ln["gamma"], ln["beta"], ln["out"], ln["mean"], ln["rstd"], ln["tickets"])
+        assert ln["tickets"].dtype == torch.int32 and ln["tickets"].numel() >= (M + 127) // 128
+        a.ln_gamma, a.ln_beta = ln["gamma"].data_ptr(), ln["beta"].data_ptr()
+        a.ln_out, a.ld_ln = ln["out"].data_ptr(), _rowmajor(ln["out"])
+        a.ln_mean, a.ln_rstd = ln["mean"].data_ptr(), ln["rstd"].data_ptr()
+        a.ln_tickets, a.ln_eps = ln["tickets"].data_ptr(), float(ln.get("eps", 1e-12))
     if not _launch:
         return a
     L.check(L.load().imt_gemm(ctypes.byref(a), _stream()), "imt_gemm")

@@ -109,6 +109,21 @@ typedef struct imt_gemm_args {
                              producer waves, K a whole number of tiles), 6 = 256 x 256 tiles (NT / NN, K a whole
                              number of tiles) */
   int32_t force_pipeline; /* reserved */
+  /* LayerNorm of the finished rows of C, in the same launch (HF BertSelfOutput / BertOutput, src/bert_seq2seq.py:84-90,
+   * 139-143: LayerNorm(dropout(dense(x)) + input) with the bias / dropout / residual epilogue above).  ln_out != NULL:
+   * ln_out[M,N] (ld_ln, type c_dtype) = LayerNorm(C rows; ln_gamma, ln_beta, ln_eps), ln_mean / ln_rstd fp32 [M] (what
+   * imt_layernorm_bwd takes).  C still receives the LayerNorm INPUT.  The default build runs imt_layernorm_fwd behind the
+   * GEMM (C and ln_out contiguous).  A build with -DIMT_LN_TICKET=1 normalises in-launch where the persistent kernel runs
+   * one tile per workgroup: C is stored write-through, each 128-row block has a ticket in ln_tickets (>= ceil(M / 128)
+   * int32, ZERO on entry, zero again on return; may be NULL: second launch), and the workgroup whose column tile completes
+   * a row block normalises it (no workgroup ever waits for another) -- measured slower than the second launch on MI355X
+   * (DESIGN.md section 5). */
+  const void* ln_gamma; const void* ln_beta;
+  void* ln_out; int64_t ld_ln;
+  float* ln_mean; float* ln_rstd;
+  int32_t* ln_tickets;
+  float ln_eps;
+  int32_t reserved_ln;
 } imt_gemm_args;
 int imt_gemm(const imt_gemm_args* a, void* stream);
 /* All weight-gradient GEMMs (IMT_TN, fp32 C += alpha * A^T B, optional a_colsum) of one transformer layer in ONE

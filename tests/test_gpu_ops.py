@@ -758,3 +758,40 @@ def test_embed_ln_and_add_ln_fused_forwards(cuda, dtype):
     s2 = (x.float() + res.float()).to(dtype)
     y2, m2, r2 = O.layernorm_fwd(s2, gam, bet)
     assert torch.equal(ssum, s2) and torch.equal(y, y2) and torch.equal(m, m2) and torch.equal(r, r2)
+
+
+# ------------------------------------------------------------------------------------------------ imt_gemm + in-launch LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(8192, 512, 512), (8128, 512, 2048), (1000, 256, 128), (8192, 1024, 256), (300, 384, 64)])
+def test_gemm_with_layernorm_of_finished_rows(cuda, dtype, shape):
+    """imt_gemm(ln_out=...): C keeps dropout(x W^T + b) + resid, ln_out = LayerNorm(C) -- in the GEMM's own launch for
+    one-tile-per-workgroup launches of the persistent kernel (row-block tickets, write-through C, the last column tile of
+    a row block normalises it), behind it otherwise.  Against the two-launch path (same C bit for bit; LayerNorm within
+    round-off: the in-launch pass sums a row in a different lane order) and torch's LayerNorm of that C."""
+    import imagetranslate_amd.hip_ops as O
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) / K ** 0.25).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.25).to(dtype).cuda()
+    b, gam, bet = (torch.randn(N, generator=g).to(dtype).cuda() for _ in range(3))
+    r = torch.randn(M, N, generator=g).to(dtype).cuda()
+    tickets = torch.zeros((M + 127) // 128 + 1, dtype=torch.int32, device="cuda")
+    for p in (0.0, 0.1):
+        ref_c = O.gemm(x, w, O.IMT_NT, bias=b, resid=r, dropout_p=p, dropout_seed=11)
+        ref_y, _, _ = O.layernorm_fwd(ref_c, gam, bet, eps=1e-12)
+        c = torch.empty_like(ref_c)
+        y = torch.empty_like(ref_c)
+        mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+        for rep in range(2):  # twice: the tickets must come back to zero
+            y.fill_(float("nan"))
+            O.gemm(x, w, O.IMT_NT, out=c, bias=b, resid=r, dropout_p=p, dropout_seed=11,
+                   ln=dict(gamma=gam, beta=bet, out=y, mean=mean, rstd=rstd, tickets=tickets, eps=1e-12))
+            torch.cuda.synchronize()
+            assert int(tickets.abs().sum()) == 0, "tickets must return to zero"
+            assert torch.equal(c, ref_c), "the LayerNorm input is the plain epilogue's result"
+            want = torch.nn.functional.layer_norm(ref_c.float(), (N,), gam.float(), bet.float(), 1e-12)
+            tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+            assert_close(y.float(), want, tol, "in-launch LayerNorm vs torch")
+            assert_close(y.float(), ref_y.float(), 1e-5 if dtype == torch.float32 else 8e-3, "in-launch LayerNorm vs the two-launch path")
+            assert_close(mean, ref_c.float().mean(1), 1e-5 if dtype == torch.float32 else 1e-4, "row means")
+            assert_close(rstd, 1.0 / torch.sqrt(ref_c.float().var(1, unbiased=False) + 1e-12), 1e-4, "row rstd")
