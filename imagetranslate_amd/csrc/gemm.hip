@@ -764,8 +764,10 @@ IMT_DEVICE void ln_finished_rows(const EpiParams& ep, int m0, int rows, int M, i
   }
 }
 
+// (not inlined: inlined into the persistent kernel its registers pushed the kernel past the 256 a wave gets at two waves per
+// SIMD and the main loop spilled)
 template <typename T>
-IMT_DEVICE void ln_rowblock_tail(const EpiParams& ep, char* lds, int m0, int row_block, int nbx, int M, int N) {
+__device__ __attribute__((noinline)) void ln_rowblock_tail(const EpiParams& ep, char* lds, int m0, int row_block, int nbx, int M, int N) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's C stores have completed (written through)
   __syncthreads();
   int* flag = reinterpret_cast<int*>(lds);
