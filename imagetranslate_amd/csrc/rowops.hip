@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnSrc<T> src, const T* __re
 // Each wave walks `rows_per_wave` rows, keeps per-column partial dgamma/dbeta in registers, the WPB waves of
 // a block combine through LDS and issue one fp32 atomic per column per block.
 template <typename T, int NCH, int WPB>
-__global__ __launch_bounds__(WPB * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(WPB * 64, ((WPB == 8 && NCH <= 2 && sizeof(T) == 2) ? 4 : 1)) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
