@@ -196,6 +196,7 @@ SIGNATURES = {
     "imt_comm_destroy": (c_int, [_P]),
     "imt_set_gemm_share_cus": (c_int, [c_int]),
     "imt_debug_spin": (c_int, [c_int, c_int, c_int, c_int64, _P]),
+    "imt_abi_sizeof": (c_int, [ctypes.c_char_p]),
     "imt_prof_enable": (c_int, [c_int]),
     "imt_prof_report": (c_int, [POINTER(ProfRow), c_int]),
     "imt_stack_workspace_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int, c_int]),
@@ -220,6 +221,12 @@ class ImtError(RuntimeError):
     pass
 
 
+ABI_STRUCTS = {"imt_gemm_args": GemmArgs, "imt_attn_args": AttnArgs, "imt_prof_row": ProfRow, "imt_attn_block": AttnBlock,
+               "imt_layer_desc": LayerDesc, "imt_stack_desc": StackDesc, "imt_stack_io": StackIO,
+               "imt_attn_decode_args": AttnDecodeArgs, "imt_decode_io": DecodeIO, "imt_beam_args": BeamArgs,
+               "imt_mass_args": MassArgs}
+
+
 def load():
     """Load libimt_hip.so and bind every declared symbol.  Raises (never falls back) if it is absent."""
     global _lib
@@ -234,6 +241,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the structures of this binding must be the library's, field for field: compare sizes once (a library built from another
+    # revision of include/imt_hip.h would otherwise receive shifted fields)
+    for cname, cls in ABI_STRUCTS.items():
+        want = lib.imt_abi_sizeof(cname.encode())
+        if want != ctypes.sizeof(cls):
+            raise ImtError("imagetranslate_amd: %s is %d bytes in %s but %d in this binding -- rebuild the library "
+                           "(python -c 'import __graft_entry__ as g; g.build()')" % (cname, want, LIB_PATH, ctypes.sizeof(cls)))
     _lib = lib
     return lib
 

@@ -117,3 +117,13 @@ extern "C" int imt_debug_spin(int blocks, int threads, int lds_bytes, int64_t cy
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
+
+extern "C" int imt_abi_sizeof(const char* name) {
+  if (!name) return -1;
+#define IMT_SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T)
+  IMT_SZ(imt_gemm_args); IMT_SZ(imt_attn_args); IMT_SZ(imt_prof_row); IMT_SZ(imt_attn_block); IMT_SZ(imt_layer_desc);
+  IMT_SZ(imt_stack_desc); IMT_SZ(imt_stack_io); IMT_SZ(imt_attn_decode_args); IMT_SZ(imt_decode_io); IMT_SZ(imt_beam_args);
+  IMT_SZ(imt_mass_args);
+#undef IMT_SZ
+  return -1;
+}

@@ -45,6 +45,12 @@ const char* imt_last_error(void);
  * bracketed by two hipEvents recorded on the launch stream.  imt_prof_report waits for the recorded events
  * (host-side), aggregates per kernel kind and clears the log.  flops/bytes are the ALGORITHMIC figures of the
  * launches (2*M*N*K per GEMM; minimal operand traffic for the HBM-bound kernels).  Off by default. */
+/* sizeof() of the argument structures below as THIS library was compiled, by name ("imt_gemm_args", "imt_attn_args",
+ * "imt_prof_row", "imt_attn_block", "imt_layer_desc", "imt_stack_desc", "imt_stack_io", "imt_attn_decode_args",
+ * "imt_decode_io", "imt_beam_args", "imt_mass_args"); -1 for an unknown name.  A binding checks its own layout against it
+ * once at load time (imagetranslate_amd/_lib.py does): a stale binding then fails loudly instead of passing shifted fields. */
+int imt_abi_sizeof(const char* struct_name);
+
 typedef struct imt_prof_row {
   char kind[48];
   int64_t launches;

@@ -41,3 +41,14 @@ def test_product_path_has_no_cpu_fallback():
     from imagetranslate_amd._lib import ImtError
     with pytest.raises(ImtError):
         O.gemm(torch.zeros(8, 8), torch.zeros(8, 8), O.IMT_NT)
+
+
+def test_struct_layouts_of_binding_and_library_agree():
+    """imt_abi_sizeof: every argument structure has the same size in the ctypes binding as in the compiled library
+    (checked at load time too; here also the refusal of an unknown name)."""
+    import ctypes
+    from imagetranslate_amd import _lib as L
+    lib = L.load()
+    for cname, cls in L.ABI_STRUCTS.items():
+        assert lib.imt_abi_sizeof(cname.encode()) == ctypes.sizeof(cls), cname
+    assert lib.imt_abi_sizeof(b"no_such_struct") == -1
