@@ -901,12 +901,14 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
         load_frags_in_use_order<T, LAYOUT>(f0a, f0b, t0, t0 + TILE_BYTES, wm, wn, 0);
       }
       for (int t = 0; t < nt; ++t) {
-        asm volatile("s_barrier" ::: "memory");
         if (i == 0 && t == 0) IMT_STAMP(ep.trace, 1);
         const char* ta = smem + cur * STAGE_BYTES;
         load_frags_in_use_order<T, LAYOUT>(f1a, f1b, ta, ta + TILE_BYTES, wm, wn, 1);
         mma_step_interleaved<T, LAYOUT>(acc, f0a, f0b);
         __builtin_amdgcn_sched_barrier(0);
+        // barrier q: K tile q + 1 has landed (read below), and everyone is done with tile q - 1 (its slot is refilled).
+        // Half a tile into the iteration: the first tile of a launch does not wait for the second one to land
+        asm volatile("s_barrier" ::: "memory");
         const int nxt = (cur + 1 == WS_NST) ? 0 : cur + 1;
         const char* tn = smem + nxt * STAGE_BYTES;  // K tile t + 1 (past the last one: read and never used)
         load_frags_in_use_order<T, LAYOUT>(f0a, f0b, tn, tn + TILE_BYTES, wm, wn, 0);
