@@ -1587,10 +1587,17 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     tail.A = reinterpret_cast<const char*>(a->A) + a_off * es;
     tail.B = reinterpret_cast<const char*>(a->B) + b_off * es;
     body.K = kb; body.accumulate = 1; body.bias = nullptr; body.resid = nullptr;
-    tail.ln_out = nullptr;  // the LayerNorm (if any) follows the complete product
-    const int rc = imt_gemm(&tail, stream);
+    tail.ln_out = nullptr; body.ln_out = nullptr;  // the LayerNorm (if any) follows the complete product
+    if (a->ln_out) {
+      IMT_CHECK_ARG(a->ln_gamma && a->ln_beta, "imt_gemm: ln_out needs ln_gamma and ln_beta");
+      IMT_CHECK_ARG(a->c_dtype == a->dtype && !a->accumulate, "imt_gemm: ln_out needs C of the compute type, no accumulate");
+      IMT_CHECK_ARG(a->ldc == a->N && a->ld_ln == a->N, "imt_gemm: ln_out behind a GEMM that cannot normalise in-launch needs contiguous C and ln_out");
+    }
+    int rc = imt_gemm(&tail, stream);
     if (rc != IMT_OK) return rc;
-    return imt_gemm(&body, stream);
+    rc = imt_gemm(&body, stream);
+    if (rc != IMT_OK || !a->ln_out) return rc;
+    return imt_layernorm_fwd(a->dtype, a->C, a->ln_gamma, a->ln_beta, a->ln_out, a->ln_mean, a->ln_rstd, a->M, a->N, a->ln_eps, 0.f, 0, stream);
   }
   const int64_t nblocks = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN) * splits;
   // kernel variant: 1 = register-staged double buffer (2 blocks/CU), 2 = LDS-DMA 3-stage ring (1 block/CU),

@@ -20,6 +20,17 @@
                   toy_seq2seq.pt by tests/util.py:beam_state_dict (matrices x2, EOS bias) so that hypotheses finish
                   at different steps; text (beam 1 / 4, with and without unpadding) and image-only captioning.
                   The reference has no test or fixture for beam search (parity unpinned).
+* beam_step1_kat.pt: the REFERENCE's own src/seq_gen.py BeamDecoder.forward run un-modified (imported from /root/reference/src)
+                  on top of THIS repo's oracle model with max_len=2 -- only iteration i = 1 executes, which is the part of
+                  the loop that runs on torch >= 1.5 (the true division of :216 sits under ``if i > 1``): encode, first-token
+                  handling, decoder call, log_softmax, EOS zeroing, length penalty, top-k over V, the cat of the chosen word
+                  (src/seq_gen.py:94-131,133-203,225-233).  Recorded: the arguments / results of its ``torch.topk`` call and
+                  the token rows it returns, for beam 1 / 4 / 5 on the text path and beam 3 on the ``images=`` path.
+* marshal_kat/  : the REFERENCE's own src/create_mt_batches.py ``write()`` (imported) on a 50-line parallel corpus and on
+                  the monolingual source side, with a tokenizer its own src/textprocessor.py trains and re-loads:
+                  corpus, tokenizer files (vocab.json / merges.txt / langs) and the two marshal files it wrote.
+* options_kat.json: every option of the REFERENCE's own src/option_parser.py parsers (flag strings, dest, type, action,
+                  default), read from the parser objects it builds.
 """
 import json
 import os
@@ -183,10 +194,135 @@ def make_config_kat():
     json.dump(out, open(os.path.join(HERE, "config_kat.json"), "w"), indent=1)
 
 
+def _ref_beam_step1(ref_gen, model, beam, **inp):
+    """Runs the reference's BeamDecoder.forward as it is, with max_len=2 (one iteration), recording its torch.topk call."""
+    rec = {}
+    real_topk = torch.topk
+
+    def spy(x, *a, **kw):
+        out = real_topk(x, *a, **kw)
+        rec["scores_in"] = x.detach().clone()
+        rec["top_scores"], rec["indices"] = out[0].detach().clone(), out[1].detach().clone()
+        return out
+    torch.topk = spy
+    try:
+        with torch.no_grad():
+            toks = ref_gen.BeamDecoder(model, beam_width=beam)(pad_idx=0, max_len=2, **inp)
+            padded = ref_gen.BeamDecoder(model, beam_width=beam)(pad_idx=0, max_len=2, unpad_output=False, **inp)
+    finally:
+        torch.topk = real_topk
+    return {"beam": beam, "tokens": [t.clone() for t in toks], "tokens_padded": [t.clone() for t in padded],
+            "top_scores": rec["top_scores"], "indices": rec["indices"],
+            "row_logsumexp_check": torch.logsumexp(rec["scores_in"], 1) if beam == 1 else None}
+
+
+def make_beam_step1_kat():
+    sys.path.insert(0, "/root/reference/src")
+    import seq_gen as ref_gen  # the reference's own file, un-modified
+    from oracle import reference_model as R
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import beam_inputs, beam_state_dict, caption_beam_inputs
+    fx = torch.load(os.path.join(HERE, "toy_seq2seq.pt"), weights_only=True)
+    gold_beam = torch.load(os.path.join(HERE, "toy_beam.pt"), weights_only=True)
+    tp = R.SyntheticTextProcessor(1000)
+    kw = dict(lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512, num_attention_heads=4)
+    m = R.Seq2Seq(tp, **kw)
+    m.load_state_dict(beam_state_dict(fx["state_dict"]))
+    m.eval()
+    res = {"source": "rasoolims/ImageTranslate src/seq_gen.py BeamDecoder.forward(max_len=2) on oracle/reference_model.py"}
+    for beam in (1, 4, 5):
+        res["text_beam%d" % beam] = _ref_beam_step1(ref_gen, m, beam, **beam_inputs())
+    # a first token that IS the end-of-sentence id: rows zeroed by :194-195, ties in top-k (which order torch.topk gives them
+    # in is recorded, not assumed)
+    inp = beam_inputs()
+    inp["first_tokens"] = torch.tensor([5, 4, 5, 4, 5, 5])
+    res["text_beam4_eos_first"] = _ref_beam_step1(ref_gen, m, 4, **inp)
+    cap = R.ImageCaptioning(tp, image_feat_dim=64, **kw)
+    cap.load_state_dict({**beam_state_dict(fx["state_dict"]), **gold_beam["caption_beam3"]["extra_state"]})
+    cap.eval()
+    res["caption_beam3"] = _ref_beam_step1(ref_gen, cap, 3, **caption_beam_inputs())
+    torch.save(res, os.path.join(HERE, "beam_step1_kat.pt"))
+    for k, v in res.items():
+        if isinstance(v, dict):
+            print(k, [t.tolist() for t in v["tokens"]][:3])
+
+
+def make_marshal_kat():
+    """Reference create_mt_batches.write() -> marshal fixtures (data: corpus, tokenizer vocabulary, the bytes it wrote)."""
+    import pickle
+    import random
+    import shutil
+    sys.path.insert(0, "/root/reference/src")
+    import create_mt_batches as ref_cmb
+    import textprocessor as ref_tp
+    out = os.path.join(HERE, "marshal_kat")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(os.path.join(out, "tok"))
+    rnd = random.Random(50)
+    en = ["the", "cat", "dog", "sees", "a", "red", "house", "and", "runs", "to", "green", "tree", "under", "sun", "quickly"]
+    fa = ["in", "gorbe", "sag", "mibinad", "yek", "ghermez", "khane", "va", "midavad", "be", "sabz", "derakht", "zire", "aftab", "tond"]
+    with open(os.path.join(out, "src.txt"), "w") as fs, open(os.path.join(out, "dst.txt"), "w") as fd:
+        for i in range(50):
+            n, k = rnd.randint(1, 14), rnd.randint(1, 14)
+            fs.write(" ".join(rnd.choice(en) for _ in range(n)) + "\n")
+            fd.write(("" if i == 17 else " ".join(rnd.choice(fa) for _ in range(k))) + "\n")  # line 17: empty target -> skipped
+    train_txt = os.path.join(out, "_train.txt")
+    with open(train_txt, "w") as fw:
+        for _ in range(20):
+            fw.write(open(os.path.join(out, "src.txt")).read())
+            fw.write(open(os.path.join(out, "dst.txt")).read())
+    tp = ref_tp.TextProcessor()
+    try:
+        tp.train_tokenizer(paths=[train_txt], vocab_size=90, to_save_dir=os.path.join(out, "tok"), languages={"<en>": 0, "<fa>": 1})
+    except Exception as e:  # TextProcessor.save: tokenizers 0.22 refuses a directory; the training itself has run
+        print("reference TextProcessor.save failed as SURVEY 2#13 says:", type(e).__name__)
+    os.remove(train_txt)
+    for f in os.listdir(os.path.join(out, "tok")):
+        os.remove(os.path.join(out, "tok", f))
+    tp.tokenizer.save_model(os.path.join(out, "tok"))  # vocab.json + merges.txt, the layout its __init__ reads
+    with open(os.path.join(out, "tok", "langs"), "wb") as fp:
+        pickle.dump(tp.languages, fp)  # what its save() writes next (src/textprocessor.py:44-45)
+    tp = ref_tp.TextProcessor(os.path.join(out, "tok"))  # re-loaded the reference's way
+    src_lang, dst_lang = tp.token_id("<en>"), tp.token_id("<fa>")
+    ref_cmb.write(text_processor=tp, output_file=os.path.join(out, "mt.marshal"), src_txt_file=os.path.join(out, "src.txt"),
+                  src_lang=src_lang, dst_txt_file=os.path.join(out, "dst.txt"), dst_lang=dst_lang, min_len=3, max_len=30)
+    ref_cmb.write(text_processor=tp, output_file=os.path.join(out, "mass.marshal"), src_txt_file=os.path.join(out, "src.txt"),
+                  src_lang=src_lang, min_len=1, max_len=175)
+    import marshal
+    ex = marshal.load(open(os.path.join(out, "mt.marshal"), "rb"))
+    mono = marshal.load(open(os.path.join(out, "mass.marshal.0"), "rb"))
+    json.dump({"source": "rasoolims/ImageTranslate src/create_mt_batches.py write(), src/textprocessor.py",
+               "src_lang_id": src_lang, "dst_lang_id": dst_lang, "n_parallel": len(ex), "n_mono": len(mono),
+               "min_len_parallel": 3, "max_len_parallel": 30, "vocab_size": tp.tokenizer.get_vocab_size(),
+               "sample_line": "the cat sees a red house", "sample_ids": tp.tokenize_one_sentence_with_langid("the cat sees a red house", src_lang)},
+              open(os.path.join(out, "meta.json"), "w"), indent=1)
+    print("marshal_kat:", len(ex), "parallel,", len(mono), "monolingual examples; vocab", tp.tokenizer.get_vocab_size())
+
+
+def make_options_kat():
+    sys.path.insert(0, "/root/reference/src")
+    import option_parser as ref_op
+    out = {"source": "rasoolims/ImageTranslate src/option_parser.py"}
+    for name in ("get_lm_option_parser", "get_img_options_parser"):
+        parser = getattr(ref_op, name)()
+        opts = []
+        for o in parser.option_list:
+            if o.dest is None:  # --help
+                continue
+            opts.append({"flags": o._short_opts + o._long_opts, "dest": o.dest, "type": o.type, "action": o.action,
+                         "default": parser.defaults.get(o.dest)})
+        out[name] = opts
+    json.dump(out, open(os.path.join(HERE, "options_kat.json"), "w"), indent=1)
+    print("options_kat:", {k: len(v) for k, v in out.items() if isinstance(v, list)})
+
+
 if __name__ == "__main__":
     make_config_kat()
     make_loss_kat()
     make_toy()
     make_beam_kat()
     make_beam()
+    make_beam_step1_kat()
+    make_marshal_kat()
+    make_options_kat()
     print("wrote", os.listdir(HERE))

@@ -7,17 +7,21 @@ checked here, through the module API, on the same weights and batches as the ora
 The FULL C1 batch is used (B = 64: 8128 target rows; 8128 = 127 * 64 is also what lets the decoder's weight gradients take
 the grouped launch, whose K -- the token count -- must be a whole number of 64-token tiles); the oracle's forward + backward
 of it takes a few seconds on the box's host cores, and is computed once per batch variant.
-Tolerances: fp32 compute mode 1e-4 relative on log-probs, 3e-4 on gradients through the 12-layer stack (north_star:
-"fp32 logits and grads within 1e-4 relative" -- the toy-size tests hold 1e-4 / 2e-4; at 12 layers x d=512 the
-accumulated fp32 round-off of two independent summation orders is ~2e-4 on the deepest gradients), argmax bit-exact;
+Tolerances: fp32 compute mode 1e-4 relative on log-probs AND on gradients through the 12-layer stack (north_star:
+"fp32 logits and grads within 1e-4 relative"), argmax bit-exact.  Rounds 1-2 held the gradients to 3e-4 on an asserted
+argument about summation orders; round 3 measured it against an fp64 run of the oracle (test_c1_fp32_against_fp64_truth,
+profiles/r03_fp64_truth_c1.txt): over all 190 gradient tensors the HIP fp32 path is within 1.9e-5 of the truth and the fp32
+oracle within 1.6e-5, so 1e-4 holds with a 3x margin for HIP-vs-oracle as well;
 bf16 mode (the benchmarked arithmetic, bf16 storage + fp32 accumulate) 4e-2 on log-probs, 1e-1 on gradients."""
+import copy
 import ctypes
+import os
 
 import pytest
 import torch
 
 from oracle import reference_model as R
-from tests.util import assert_close
+from tests.util import assert_close, fp64_truth_report
 
 pytestmark = pytest.mark.gpu
 
@@ -85,7 +89,28 @@ def _oracle_run(ref, args):
     targets = args[1][:, 1:][args[3][:, 1:]]
     loss = R.SmoothedNLLLoss(ignore_index=0)(lp, targets).mean()
     loss.backward()
-    return lp.detach(), float(loss.detach()), {k: dict(ref.named_parameters())[k].grad.clone() for k in GRAD_KEYS}
+    return lp.detach(), float(loss.detach()), {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+
+
+def _oracle64(ref, args):
+    """The oracle in fp64 on the same weights and batch: ground truth for the 1e-4 bar (about a minute on the box's cores)."""
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    lp = ref64(*args, log_softmax=True)
+    targets = args[1][:, 1:][args[3][:, 1:]]
+    loss = R.SmoothedNLLLoss(ignore_index=0)(lp, targets).mean()
+    loss.backward()
+    return lp.detach(), float(loss.detach()), {k: p.grad for k, p in ref64.named_parameters() if p.grad is not None}
+
+
+def write_truth_log(name, lines):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "fp64_truth_%s.txt" % name), "w") as fw:
+            fw.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
 
 
 def _kinds_of_step(fn):
@@ -129,11 +154,48 @@ def test_c1_fp32_parity_and_dispatch(pair, ragged):
     assert abs(float(loss.detach()) - loss_ref) <= 1e-5 * abs(loss_ref), (float(loss.detach()), loss_ref)
     ours_g = dict(ours.named_parameters())
     for k in GRAD_KEYS:
-        assert_close(ours_g[k].grad, g_ref[k], 3e-4, "C1 fp32 grad " + k)
+        assert_close(ours_g[k].grad, g_ref[k], 1e-4, "C1 fp32 grad " + k)
     # the dispatch bench.py times
     assert kinds.get("gemm_ws_f32_nn", 0) + kinds.get("gemm_ws_f32_nt", 0) >= 30, kinds
     assert kinds.get("gemm_f32_tn_grouped", 0) == 12, kinds
     assert any(k.startswith("xent_fused") for k in kinds), kinds
+
+
+def test_c1_fp32_against_fp64_truth(pair):
+    """north_star: "fp32 logits and grads within 1e-4 relative".  Ground truth = the oracle run in fp64 on the full C1 batch;
+    the HIP fp32 path must be within 1e-4 of it (max |a-t| / max |t|) on the log-probs and on EVERY parameter gradient
+    (word / position / type embeddings through atomics, LayerNorm gains through the 32-copy partials, the vocabulary dX through
+    the split-K slabs included), and within 2e-3 element-wise on the entries above 1 % of a tensor's maximum.  The fp32
+    oracle's own distance from the truth is printed beside each number (gpurun_out/fp64_truth_c1.txt)."""
+    ref, ours = pair
+    args = _batch()
+    lp32, loss32, g32 = _oracle(ref, args, ("c1", False))
+    lp64, loss64, g64 = _oracle64(ref, args)
+    ours.set_compute_dtype(torch.float32)
+    log = []
+    with torch.no_grad():
+        lp = ours(*args, log_softmax=True)
+    fp64_truth_report("log-probs [8128, 30000]", lp, lp32, lp64, 1e-4, 2e-3, log)
+    assert torch.equal(lp.argmax(-1).cpu(), lp64.argmax(-1)), "argmax token ids must equal the fp64 truth's"
+    del lp, lp64
+    ours.zero_grad()
+    loss, _ = ours.loss_fused(*args)
+    loss.backward()
+    assert abs(float(loss.detach()) - loss64) <= 1e-5 * abs(loss64), (float(loss.detach()), loss64, loss32)
+    worst, worst_o = 0.0, 0.0
+    n = 0
+    try:
+        for k, p in ours.named_parameters():
+            if k not in g64 or p.grad is None:
+                continue
+            if float(g64[k].abs().max()) < 1e-9:  # zero in exact arithmetic (attention key biases)
+                continue
+            e, eo = fp64_truth_report("grad " + k, p.grad, g32[k], g64[k], 1e-4, 2e-3, log)
+            worst, worst_o, n = max(worst, e), max(worst_o, eo), n + 1
+    finally:
+        log.append("tensors %d; worst hip-fp32 %.3e, worst oracle-fp32 %.3e" % (n, worst, worst_o))
+        write_truth_log("c1", log)
+    assert n >= 150, n
 
 
 @pytest.mark.parametrize("ragged", [False, True], ids=["c1", "c1ragged"])

@@ -320,3 +320,28 @@ def test_decode_step_matches_full_decoder(cuda):
     for t in range(T):
         inc.step(t, B, 1, toks[:, t].contiguous(), types[:, 0].contiguous(), slots, out)
         assert_close(out, full[:, t], 1e-4, "decode step %d" % t)
+
+
+@pytest.mark.parametrize("name", ["text_beam1", "text_beam4", "text_beam5", "text_beam4_eos_first", "caption_beam3"])
+@pytest.mark.parametrize("kv_cache", [True, False], ids=["kv_cache", "recompute"])
+def test_beam_first_step_against_reference_beam_decoder(cuda, name, kv_cache):
+    """The product against what the REFERENCE's own src/seq_gen.py BeamDecoder.forward returned when run un-modified with
+    max_len=2 on the oracle model (tests/golden/beam_step1_kat.pt): encode, first-token handling, log-softmax, length
+    penalty and the top-k over V of step 1, bit-exact token ids (fp32 compute)."""
+    from imagetranslate_amd.seq_gen import BeamDecoder
+    from tests.test_oracle_pinning import check_beam_step1
+    kat = torch.load(os.path.join(GOLD, "beam_step1_kat.pt"), weights_only=True)
+    case = kat[name]
+    if name.startswith("caption"):
+        gold = torch.load(os.path.join(GOLD, "toy_beam.pt"), weights_only=True)
+        _, ours = _pair("ImageCaptioning", state={**_fixture_state(), **gold["caption_beam3"]["extra_state"]}, image_feat_dim=64)
+        inp = caption_beam_inputs()
+    else:
+        _, ours = _pair(state=_fixture_state())
+        inp = beam_inputs()
+    if name.endswith("eos_first"):
+        inp["first_tokens"] = torch.tensor([5, 4, 5, 4, 5, 5])
+    dec = BeamDecoder(ours, beam_width=case["beam"], kv_cache=kv_cache)
+    toks = dec(pad_idx=0, max_len=2, **inp)
+    padded = dec(pad_idx=0, max_len=2, unpad_output=False, **inp)
+    check_beam_step1(case, toks, padded, None, inp["first_tokens"])

@@ -508,3 +508,39 @@ def test_training_mode_dropout_is_consistent_between_forward_and_backward(cuda):
             p[idx] = old
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - g) <= 0.08 * max(abs(fd), abs(g)) + 2e-5, "%s%s: analytic %.6g vs finite-difference %.6g" % (key, idx, g, fd)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_intermediate_size_not_a_multiple_of_the_k_tile(cuda, dtype):
+    """ff = 1032: the FFN-down projection has K = 1032 (not a whole number of 64- / 32-element K tiles, and >= 16 tiles long),
+    so imt_gemm takes its ragged-tail + whole-tile-body split; with dropout off (eval, dev loss, decoding) the dense +
+    LayerNorm call carries ln_out through that split.  Eval forward, train-mode step and beam search against the oracle."""
+    ref, ours = _pair(ff=1032)
+    ours.set_compute_dtype(dtype)
+    tol, gtol = (1e-4, 2e-4) if dtype == torch.float32 else (3e-2, 8e-2)
+    b = _toy_batch()
+    args = (b["src_texts"], b["dst_texts"], b["src_pad_mask"], b["dst_pad_mask"], b["src_langs"], b["dst_langs"])
+    lp_ref = ref(*args, log_softmax=True)
+    with torch.no_grad():
+        lp = ours(*args, log_softmax=True)       # eval mode: dropout 0 -> the split path with ln_out
+    assert_close(lp, lp_ref, tol, "log-probs, ff=1032")
+    targets = b["dst_texts"][:, 1:][b["dst_pad_mask"][:, 1:]]
+    loss_ref = R.SmoothedNLLLoss(ignore_index=0)(lp_ref, targets).mean()
+    loss_ref.backward()
+    ours.zero_grad()
+    loss, _ = ours.loss_fused(*args)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(loss_ref), rel=10 * tol)
+    for k in ("decoder.decoder.layer.1.output.dense.weight", "encoder.encoder.layer.0.intermediate.dense.weight",
+              "encoder.encoder.layer.1.output.LayerNorm.weight"):
+        assert_close(_grad_of(ours, k), _grad_of(ref, k), gtol, "grad " + k)
+    if dtype == torch.float32:
+        from imagetranslate_amd.seq_gen import BeamDecoder
+        from oracle.seq_gen import BeamDecoder as OracleBeam
+        n = 4
+        kw = dict(src_inputs=b["src_texts"][:n], src_sizes=b["src_pad_mask"][:n].sum(1), first_tokens=torch.full((n,), 6),
+                  src_mask=b["src_pad_mask"][:n], src_langs=b["src_langs"][:n], tgt_langs=b["dst_langs"][:n], pad_idx=0, max_len=9)
+        exp = OracleBeam(ref, beam_width=3)(**kw)
+        got = BeamDecoder(ours, beam_width=3)(**kw)          # imt_decode_step through the same dense + LayerNorm call
+        assert [g.tolist() for g in got] == [e.tolist() for e in exp]
+    ours.set_compute_dtype(torch.float32)

@@ -17,6 +17,35 @@ def assert_close(a, b, tol, what=""):
     return e
 
 
+def truth_errors(a: torch.Tensor, truth: torch.Tensor):
+    """(max |a-t| / max |t|,  max over entries with |t| >= 1 % of max |t| of |a-t| / |t|) against an fp64 ground truth."""
+    a = a.detach().double().cpu()
+    t = truth.detach().double().cpu()
+    assert a.shape == t.shape, (tuple(a.shape), tuple(t.shape))
+    m = float(t.abs().max())
+    if m == 0.0:
+        return float(a.abs().max()), 0.0
+    d = (a - t).abs()
+    big = t.abs() >= 1e-2 * m
+    return float(d.max()) / m, float((d[big] / t.abs()[big]).max())
+
+
+def fp64_truth_report(name, ours, oracle32, truth, tol, elem_tol, log=None):
+    """north_star's bar, measured against an fp64 run of the oracle: the HIP fp32 result within ``tol`` of the truth in the
+    max norm and within ``elem_tol`` element-wise on the entries above 1 % of the maximum; the fp32 oracle's own distance
+    from the truth is printed beside it (and written to ``log``), so that a bar is evidenced, not asserted."""
+    e_o, r_o = truth_errors(ours, truth)
+    e_f, r_f = truth_errors(oracle32, truth)
+    line = "%-62s hip-fp32 %.2e (elem %.2e) | oracle-fp32 %.2e (elem %.2e)" % (name, e_o, r_o, e_f, r_f)
+    print(line)
+    if log is not None:
+        log.append(line)
+    assert torch.isfinite(ours.detach().float()).all(), name
+    assert e_o <= tol, "%s: %.3e > %.1e against the fp64 truth (fp32 oracle: %.3e)" % (name, e_o, tol, e_f)
+    assert r_o <= elem_tol, "%s: element-wise %.3e > %.1e against the fp64 truth (fp32 oracle: %.3e)" % (name, r_o, elem_tol, r_f)
+    return e_o, e_f
+
+
 TOL = {torch.float32: 1e-4, torch.bfloat16: 2.5e-2}
 
 
