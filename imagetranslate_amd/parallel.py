@@ -171,7 +171,9 @@ class GradSync:
         projection every rank uses in this step (batches of one language direction on all ranks) -- the other heads have
         no gradient anywhere and are left out of the exchange, which is what DDP's ``find_unused_parameters=True`` does
         at src/train_image_mt.py:73 for parameters unused on every rank (61.6 MB of fp32 zeros at C1).  None: exchange
-        everything (always correct)."""
+        everything (always correct).  Constraint: only for steps that are their own accumulation window (``--acc 1``);
+        ``train_step`` refuses the hint inside a window, where a head idle in this micro-step may hold gradients of an
+        earlier one."""
         sched = self._schedules.get(active_head)
         if sched is not None:
             return sched
@@ -277,6 +279,13 @@ def train_step(model, optimizer, batch, sync: Optional[GradSync] = None, clip: f
     exchange also happens per micro-step, as under DDP.  ``loss_weight``: ``mtl_weight`` of the captioning trainer
     (src/train_captioning.py:83).  ``active_head``: see GradSync.bucket_schedule."""
     if sync is not None:
+        # an idle head is left out of the exchange but the clip / optimizer kernels scale the WHOLE gradient buffer by 1/world:
+        # inside an accumulation window a head that was active in an earlier micro-step would be shrunk again in every
+        # micro-step it sits out.  The hint is therefore only valid for steps that are their own window (acc = 1).
+        if active_head is not None and sync.world_size > 1 and (not update or getattr(sync, "_window_open", False)):
+            raise ValueError("train_step: active_head cannot be combined with gradient accumulation under data parallelism "
+                             "(pass active_head=None: exchange every head)")
+        sync._window_open = not update
         sync.begin_step(active_head)
     loss, ntokens = _loss_of(model, batch, epsilon)
     (loss if loss_weight == 1.0 else loss * loss_weight).backward()

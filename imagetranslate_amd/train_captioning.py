@@ -32,12 +32,18 @@ class ImageCaptionTrainer(ImageMTTrainer):
     # one image batch (src/train_captioning.py:40-58,76-97)
     def caption_step(self, batch, accum: int = 1):
         model, tp = self.model, self.model.text_processor
+        # a batch without a single target token is decided on the host BEFORE anything is enqueued; under data parallelism
+        # this rank still runs the step's collectives (on its unchanged gradient buffer) and counts the micro-step, so every
+        # rank issues the same all-reduces and steps the optimizer at the same time
+        if not bool(batch["caption_mask"][:, 1:].any()):
+            if self.sync is not None and self.world_size > 1:
+                self.sync.begin_step()
+                self._finish_micro_step(None, accum, self.sync.finish())
+            return 0.0, 0
         if self.sync is not None:
             self.sync.begin_step()
         loss, ntokens = model.loss_fused(tgt_inputs=batch["captions"], tgt_mask=batch["caption_mask"], pad_idx=tp.pad_token_id(),
                                          tgt_langs=batch["langs"], batch=batch)
-        if ntokens == 0:
-            return 0.0, 0
         loss.backward()
         scale = self.sync.finish() if self.sync is not None else 1.0
         self._finish_micro_step(loss, accum, scale)
@@ -98,9 +104,9 @@ class ImageCaptionTrainer(ImageMTTrainer):
                 print("skipping batch:", repr(err))
                 self.optimizer.zero_grad()
                 continue
-            if n == 0:
+            if n == 0 and self.world_size == 1:
                 continue
-            step += 1
+            step += 1  # (an empty batch of a multi-rank job counts: the other ranks counted theirs)
             meter.add(loss, n)
             if step % log_every == 0:
                 mean, tokens = meter.read()
@@ -132,7 +138,7 @@ class ImageCaptionTrainer(ImageMTTrainer):
 
     @staticmethod
     def train(options):
-        reject_off_path(options)
+        reject_off_path(options, lm_supported=True)
         rank, world = init_distributed()
         random.seed(options.seed)
         torch.manual_seed(options.seed)

@@ -46,9 +46,9 @@ class ImageMTTrainer:
     # one MT batch (src/train_image_mt.py:239-295)
     def mt_step(self, batch, accum: int = 1, loss_weight: float = 1.0):
         batch = {k: (v[0] if isinstance(v, list) else v) for k, v in batch.items()}
-        self.micro_step += 1
         loss, ntokens = train_step(self.model, self.optimizer, batch, sync=self.sync, clip=self.clip,
-                                   update=(self.micro_step % max(1, accum) == 0), loss_weight=loss_weight)
+                                   update=((self.micro_step + 1) % max(1, accum) == 0), loss_weight=loss_weight)
+        self.micro_step += 1  # only a micro-step whose backward ran counts (a failing batch is skipped, train_epoch)
         return loss.detach(), int(ntokens)  # the loss stays on the device: reading it here would stall the host every step
 
     # one MASS batch (src/train_image_mt.py:186-236): mask a span, recover it with its original positions
@@ -168,10 +168,16 @@ def init_distributed():
     return rank, world
 
 
-def reject_off_path(options):
+def reject_off_path(options, lm_supported: bool = False):
+    """Flags whose feature is not built are refused, never silently ignored: a requested pretrained initialisation or a
+    resumed optimizer that quietly trains from scratch is worse than an error."""
     for flag, val in (("--dict", options.dict_path), ("--langs", options.bt_langs)):
         if val:
             raise NotImplementedError("%s: outside the hot path (lexical proposals / back-translation scheduling, DESIGN section 7)" % flag)
+    for flag, val in (("--lm", None if lm_supported else options.lm_path), ("--cont", options.continue_train), ("--save-opt", options.save_opt)):
+        if val:
+            raise NotImplementedError("%s: not implemented by this trainer (masked-LM initialisation / pickled-optimizer resume, "
+                                      "src/train_image_mt.py:319-321,449-462); use --pretrained to continue from saved weights" % flag)
 
 
 def train(options):

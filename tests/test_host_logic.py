@@ -68,3 +68,17 @@ def test_bench_self_launch_propagates_child_failure():
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode != 0
     assert "rank" in r.stderr and "exited with code" in r.stderr
+
+
+def test_unimplemented_flags_are_refused_not_ignored():
+    """--lm (train_image_mt), --cont, --save-opt, --dict, --langs: parsed like the reference's flags, refused at use."""
+    from imagetranslate_amd.option_parser import get_img_options_parser
+    from imagetranslate_amd.train_image_mt import reject_off_path
+    for argv in (["--lm", "x"], ["--cont"], ["--save-opt"], ["--dict", "d"], ["--langs", "en,fa"]):
+        o, _ = get_img_options_parser().parse_args(argv)
+        with pytest.raises(NotImplementedError):
+            reject_off_path(o)
+    o, _ = get_img_options_parser().parse_args(["--lm", "x"])
+    reject_off_path(o, lm_supported=True)  # train_captioning adopts a pretrained MT model through --lm
+    o, _ = get_img_options_parser().parse_args([])
+    reject_off_path(o)
