@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0      # HBM3E spec (6.3 TB/s is what a float4 copy reaches, same guide)
+HBM_KINDS = ("layernorm_fwd", "layernorm_bwd", "embed_ln_fwd", "embed_fwd", "embed_bwd", "clip_adam", "xent_fused", "grad_sumsq")
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 CONFIGS = {
     # name: (B, S, T, d, heads, ff, enc, dec, V)
@@ -156,6 +159,59 @@ def profile_pass(step_fn, steps=2):
     return sorted(out, key=lambda r: -r["ms"])
 
 
+def tune_dp_policy(sync, step, fence, device, backend, probe_steps=3):
+    """Data-parallel run: two choices that cannot be made on a one-GPU box are made HERE by measurement, before the warm-up,
+    identically on every rank (times are max-reduced over the ranks, so every rank sees the same numbers and picks the same
+    minimum): (1) whether the one-tile-per-CU GEMMs with K < 1024 leave the persistent kernel for the three-workgroups-per-CU
+    one while RCCL's kernels hold CUs (imt_set_gemm_share_cus); (2) whether the gradient buckets travel
+    through torch.distributed's nccl backend or through the library's own RCCL communicator (imt_comm_*).  Each candidate
+    runs `probe_steps` real train steps.  An axis pinned by its environment variable (IMT_GEMM_SHARE_CUS / IMT_COMM) is
+    not tuned.  Returns the choice and the probe times for the JSON line."""
+    import torch.distributed as dist
+    from imagetranslate_amd import _lib as L
+    from imagetranslate_amd.parallel import RcclComm
+    lib = L.load()
+    share_axis = [None] if os.environ.get("IMT_GEMM_SHARE_CUS") is not None else [1, 0]
+    comm_axis = ["torch-" + backend]
+    rccl = None
+    if os.environ.get("IMT_COMM") is None and backend == "nccl" and sync.comm is None:
+        ok = torch.ones(1, device=device)
+        try:
+            rccl = RcclComm(dist.get_rank(), dist.get_world_size())
+        except Exception as err:  # librccl missing, ...: every rank must agree before anything is switched
+            print("[bench] imt_comm unavailable on this rank: %r" % (err,), file=sys.stderr, flush=True)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok) > 0:
+            comm_axis.append("imt-rccl")
+        else:
+            rccl = None
+    elif sync.comm is not None:
+        comm_axis = ["imt-rccl"]
+        rccl = sync.comm
+    probes = {}
+    for comm in comm_axis:
+        sync.comm = rccl if comm == "imt-rccl" else None
+        for share in share_axis:
+            if share is not None:
+                lib.imt_set_gemm_share_cus(share)
+            step()  # one untimed step per candidate (first use of a communicator / kernel variant)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(probe_steps):
+                step()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            probes[(comm, share)] = 1e3 * float(t) / probe_steps
+    best = min(probes, key=lambda k: (probes[k], k[0], -1 if k[1] is None else k[1]))
+    sync.comm = rccl if best[0] == "imt-rccl" else None
+    if best[1] is not None:
+        lib.imt_set_gemm_share_cus(best[1])
+    return {"comm": best[0], "gemm_share_cus": "env" if best[1] is None else best[1],
+            "probe_ms_per_step": {"%s,share_cus=%s" % k: round(v, 3) for k, v in probes.items()}}
+
+
 def self_launch(n):
     """python bench.py --gpus N without a launcher: start N rank processes of this script (nothing here has touched the
     GPU yet -- children are started, never exec'd into), wait for all, propagate the first failure."""
@@ -252,6 +308,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dp_policy = tune_dp_policy(sync, step, fence, device, backend) if sync is not None else None
     for _ in range(args.warmup):
         step()
     fence()
@@ -295,19 +352,34 @@ def main():
         roofline = None
         if dom is not None:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic = None
-            try:  # HBM bytes per launch of this kernel kind from the committed PMC passes (tools/collect_traffic.sh)
-                pt = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                if args.config == "c1" and world == 1:
-                    traffic = round(pt["per_kind"][dom["kind"]]["hbm_bytes_per_launch"])
-            except Exception:
-                traffic = None
+            traffic, traffic_source = None, None
+            for tf in (TRAFFIC_FILE, os.path.join("profiles", "r02_pmc_traffic.json")):
+                try:  # HBM bytes per launch of this kernel kind: a REPLAY of the committed PMC passes (tools/collect_traffic.sh),
+                      # not a measurement of this run -- PMC collection needs rocprofv3 around the process
+                    pt = json.load(open(os.path.join(ROOT, tf)))
+                    if args.config == "c1" and world == 1:
+                        traffic = round(pt["per_kind"][dom["kind"]]["hbm_bytes_per_launch"])
+                        traffic_source = tf
+                        break
+                except Exception:
+                    traffic = None
             roofline = {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": traffic,
+                        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_bytes_per_launch": round(dom["bytes"] / max(1, dom["launches"])),
                         "launches_per_step": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / max(1, dom["launches"]), 2),
                         "step_frac": round(flops / (ms_per_step * 1e-3) / 1e12 / peak, 4),
                         "step_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2)}
+        if roofline is not None:
+            # the HBM side of the roofline (north_star: achieved HBM GB/s against chip peak): every HBM-bound kernel kind of the
+            # step, algorithmic bytes per launch / event-bracketed launch time of the instrumented pass
+            hbm = []
+            for r in rows:
+                if r["kind"] in HBM_KINDS and r["launches"] > 0 and r["ms"] > 0:
+                    gbps = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                    hbm.append({"kernel": r["kind"], "launches_per_step": r["launches"], "bytes_per_launch": round(r["bytes"] / r["launches"]),
+                                "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2), "achieved_GBps": round(gbps, 1),
+                                "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4)})
+            roofline["hbm_kernels"] = hbm
         out = {
             "metric": "train tokens/sec (whole node), 6L enc-dec d=512 seq128 b64, 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -325,6 +397,7 @@ def main():
             out["config"]["adam_bytes_per_step"] = round(sum(r["bytes"] for r in adam))
         if sync is not None:
             out["config"]["grad_exchange_bytes_per_step"] = sync.exchanged_bytes(0)
+            out["config"]["dp_policy"] = dp_policy
         print("[bench] gpu: %.1f tokens/s, %.3f ms/step" % (value, ms_per_step), file=sys.stderr, flush=True)
         if args.breakdown:
             tot = sum(r["ms"] for r in rows)
