@@ -739,6 +739,218 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnP p) {
   }  IMT_STAMP(p.trace, 4);
 }
 
+// =========================================================================================== backward: fused, 129-256 keys / queries
+// The MASS shapes (BASELINE configs[4]: encoder self-attention 256 x 256, decoder cross-attention 128 x 256) took the
+// two-kernel path above: S / dP recomputed twice, Q / K / V / dO read twice, 1.25 ms of a 10.7 ms step.  Same fusion as
+// attn_bwd_fused_kernel, re-cut so that it fits 160 KiB of LDS at 256 keys: ONE workgroup (8 waves) per (batch, head),
+//   phase 0: K / V rows in registers (KEY on the lane: wave w owns keys 32w .. 32w+31 as two groups of 16), K parked in LDS
+//            once for phase 2, delta = rowsum(dO * O) and lse of all queries in LDS;
+//   then per tile of 64 QUERIES (its Q / dO rows staged through registers one tile ahead):
+//   phase 1: S, P, dP, dS for (64 queries x this wave's 32 keys); dV^T += dO^T P, dK^T += Q^T dS stay in registers over all
+//            query tiles; dS^T of the tile goes to LDS as bf16 [key][query];
+//   phase 2: QUERY on the lane: dQ[64 x dh] = dS K from LDS (wave = 16 queries x half of dh), stored at once.
+// The [key][query] tile is 32 KiB instead of 128: 82 KiB in all.  Nothing is summed across workgroups (no atomics); same
+// masks, same dropout draws as every other attention kernel.
+template <int DH, bool MASK3D>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused256_kernel(AttnP p) {
+  typedef bf16_t T;
+  constexpr int RB = DH * 2, NS = RB / 64, NDT = DH / 16, CPR = RB / 16;
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                         // [256 keys][RB]
+  char* Qt = Ks + 256 * RB;                // [64][RB]   current query tile
+  char* dOt = Qt + 64 * RB;                // [64][RB]
+  char* dST = dOt + 64 * RB;               // [256 keys][64 queries] bf16, 128-B rows
+  float* lse_s = reinterpret_cast<float*>(dST + 256 * 128);
+  float* delta_s = lse_s + 256;
+  uint8_t* qmask_s = reinterpret_cast<uint8_t*>(delta_s + 256);
+
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);
+  const int b = lid / p.H, h = lid % p.H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)b * p.Tq * p.ldq + h * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)b * p.Tk * p.ldk + h * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)b * p.Tk * p.ldv + h * DH;
+  const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)b * p.Tq * p.lddo + h * DH;
+  const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)b * p.Tq * p.ldo + h * DH;
+  const int nqt = (p.Tq + 63) / 64;
+
+  // ---- phase 0: every load requested up front, unconditionally (clamped rows / stand-in addresses)
+  frag_t kf[2][NS], vf[2][NS];
+  bool key_ok[2];
+  // one 16-byte chunk of the 64-row Q / dO tile per thread (DH = 32: the first 256 threads), prefetched one tile ahead
+  const int st_row = (int)threadIdx.x / CPR, st_c = (int)threadIdx.x % CPR;
+  const bool stager = st_row < 64;
+  u32x4 vq, vo;
+  auto prefetch = [&](int qt) {
+    const int tr = min(qt * 64 + min(st_row, 63), p.Tq - 1);
+    vq = *reinterpret_cast<const u32x4*>(Qb + (int64_t)tr * p.ldq + st_c * 8);
+    vo = *reinterpret_cast<const u32x4*>(dOb + (int64_t)tr * p.lddo + st_c * 8);
+  };
+  prefetch(0);
+  {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      load_row_frags<T, DH>(kf[kg], Kb, p.ldk, 32 * wave + 16 * kg, p.Tk);
+      load_row_frags<T, DH>(vf[kg], Vb, p.ldv, 32 * wave + 16 * kg, p.Tk);
+    }
+    frag_t of[2][NS], dof[2][NS];
+    float lse_v[2];
+    uint8_t qmv[2], kmv[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int i = 128 * ps + 16 * wave + r;
+      load_row_frags<T, DH>(of[ps], Ob, p.ldo, 128 * ps + 16 * wave, p.Tq);
+      load_row_frags<T, DH>(dof[ps], dOb, p.lddo, 128 * ps + 16 * wave, p.Tq);
+      lse_v[ps] = p.lse[((int64_t)b * p.H + h) * p.Tq + min(i, p.Tq - 1)];
+      const uint8_t* qmp = p.query_mask ? p.query_mask + (int64_t)b * p.Tq + min(i, p.Tq - 1) : reinterpret_cast<const uint8_t*>(Qb);
+      qmv[ps] = *qmp;
+    }
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int j = 32 * wave + 16 * kg + r;
+      const uint8_t* kmp = p.key_mask ? p.key_mask + (int64_t)b * p.Tk + min(j, p.Tk - 1) : reinterpret_cast<const uint8_t*>(Kb);
+      kmv[kg] = *kmp;
+    }
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int j = 32 * wave + 16 * kg + r;
+      key_ok[kg] = (j < p.Tk) ? (p.key_mask ? (kmv[kg] != 0) : true) : false;
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) *reinterpret_cast<frag_t*>(Ks + tile_off<RB>(j, 4 * ks + g)) = kf[kg][ks];  // rows >= Tk: zeros
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int i = 128 * ps + 16 * wave + r;
+      float d = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += (float)dof[ps][ks][e] * (float)of[ps][ks][e];
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      if (g == 0) {
+        delta_s[i] = d;
+        lse_s[i] = lse_v[ps];
+        qmask_s[i] = (i < p.Tq && p.query_mask) ? qmv[ps] : (uint8_t)1;
+      }
+    }
+  }
+
+  f32x4 dk[2][NDT], dv[2][NDT];
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { dk[kg][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kg][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const uint32_t dkey = dropout_key(p.seed);
+  const uint32_t tkp = (uint32_t)((p.Tk + 1) >> 1);
+  const int nks = (p.Tk + 31) / 32;
+  const int qg = wave & 3, dhalf = wave >> 2;   // phase 2: 16 queries x half of the head dimension per wave
+  constexpr int NDH = (NDT + 1) / 2;
+
+#pragma unroll 1
+  for (int qt = 0; qt < nqt; ++qt) {
+    // the staged tile: rows past Tq are zeros.  (Every wave has left phase 2 of the previous tile -- which reads neither Qt
+    // nor dOt -- only after the barrier that closed its phase 1, so these writes cannot overtake a reader.)
+    if (stager) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      const bool in = qt * 64 + st_row < p.Tq;
+      *reinterpret_cast<u32x4*>(Qt + tile_off<RB>(st_row, st_c)) = in ? vq : z;
+      *reinterpret_cast<u32x4*>(dOt + tile_off<RB>(st_row, st_c)) = in ? vo : z;
+    }
+    __syncthreads();  // tile staged (first trip: K, delta, lse too); dS^T of the previous tile fully consumed
+    if (qt + 1 < nqt) prefetch(qt + 1);
+
+    // ---- phase 1
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int j = 32 * wave + 16 * kg + r;  // this lane's key
+      f32x4 s[4], dp[4], pd[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        s[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+          mma16(s[mt], lds_frag_kcontig<T, RB>(Qt, 16 * mt, 4 * ks), kf[kg][ks]);
+          mma16(dp[mt], lds_frag_kcontig<T, RB>(dOt, 16 * mt, 4 * ks), vf[kg][ks]);
+        }
+      }
+      const uint32_t pair_base = (uint32_t)(b * p.H + h) * (uint32_t)p.Tq * tkp + (uint32_t)(j >> 1);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int i0 = qt * 64 + 16 * mt + 4 * g;  // this lane's 4 consecutive queries
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + i0), del4 = *reinterpret_cast<const f32x4*>(delta_s + i0);
+        const uint32_t qm4 = *reinterpret_cast<const uint32_t*>(qmask_s + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = i0 + e;
+          float v = s[mt][e] * p.scale + (mask_ok<MASK3D>(p, b, i, j, key_ok[kg], ((qm4 >> (8 * e)) & 0xffu) != 0) ? 0.f : -10000.0f);
+          float pv = (i < p.Tq && j < p.Tk) ? __expf(v - lse4[e]) : 0.f;
+          float dpv = dp[mt][e], pdv = pv;
+          if (p.drop_thresh) {  // (host guarantees B*H*Tq*Tk < 2^32 for this kernel)
+            const bool keep = attn_drop_keep(attn_drop_word(dkey, pair_base + (uint32_t)i * tkp), j, p.drop_thresh);
+            dpv = keep ? dpv * p.inv_keep : 0.f;
+            pdv = keep ? pv * p.inv_keep : 0.f;
+          }
+          pd[mt][e] = pdv;
+          s[mt][e] = pv * (dpv - del4[e]);  // dS[i][j]
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const frag_t pf = acc_pair_to_frag(pd[2 * u], pd[2 * u + 1]);
+        const frag_t dsf = acc_pair_to_frag(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          mma16(dv[kg][dt], lds_frag_kperm_bf16<RB>(dOt, 32 * u, 16 * dt), pf);   // dV^T[d][key] += dO^T[d][q] P[q][key]
+          mma16(dk[kg][dt], lds_frag_kperm_bf16<RB>(Qt, 32 * u, 16 * dt), dsf);   // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
+      }
+      // dS^T[key j][local queries 16mt + 4g .. +3] (bf16, 8 bytes)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int ql = 16 * mt + 4 * g;
+        bf16x4 w = {(bf16_t)s[mt][0], (bf16_t)s[mt][1], (bf16_t)s[mt][2], (bf16_t)s[mt][3]};
+        *reinterpret_cast<bf16x4*>(dST + tile_off<128>(j, ql >> 3) + ((ql & 7) << 1)) = w;
+      }
+    }
+    __syncthreads();  // dS^T of this tile complete
+
+    // ---- phase 2: dQ[q][d] = scale * sum_key dS[q][key] K[key][d]
+    f32x4 dq[NDH];
+#pragma unroll
+    for (int t = 0; t < NDH; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dhalf * NDH < NDT) {  // (uniform per wave; DH = 32 with NDT = 2: both halves hold one tile)
+#pragma unroll 2
+      for (int kstep = 0; kstep < nks; ++kstep) {
+        const frag_t fa = lds_frag_kstrided_bf16<128>(dST, 32 * kstep, 16 * qg);
+#pragma unroll
+        for (int t = 0; t < NDH; ++t) mma16(dq[t], lds_frag_kstrided_bf16<RB>(Ks, 32 * kstep, 16 * (dhalf * NDH + t)), fa);
+      }
+      const int i = qt * 64 + 16 * qg + r;
+      if (i < p.Tq) {
+        T* dQb = reinterpret_cast<T*>(p.dQ) + ((int64_t)b * p.Tq + i) * p.lddq + h * DH;
+#pragma unroll
+        for (int t = 0; t < NDH; ++t) Vec4<T>::store(dQb + 16 * (dhalf * NDH + t) + 4 * g, dq[t] * p.scale);
+      }
+    }
+  }
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+    const int j = 32 * wave + 16 * kg + r;
+    if (j < p.Tk) {
+      T* dKb = reinterpret_cast<T*>(p.dK) + ((int64_t)b * p.Tk + j) * p.lddk + h * DH;
+      T* dVb = reinterpret_cast<T*>(p.dV) + ((int64_t)b * p.Tk + j) * p.lddv + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        Vec4<T>::store(dKb + 16 * dt + 4 * g, dk[kg][dt] * p.scale);
+        Vec4<T>::store(dVb + 16 * dt + 4 * g, dv[kg][dt]);
+      }
+    }
+  }
+}
+
 int check_args(const imt_attn_args* a, bool bwd) {
   IMT_CHECK_ARG(a != nullptr, "attention: null args");
   IMT_CHECK_ARG(a->dtype == IMT_F32 || a->dtype == IMT_BF16, "attention: bad dtype");
@@ -794,6 +1006,20 @@ template <int DH, bool MASK3D> int bwd_fused_launch(const AttnP& p, hipStream_t 
   AttnP pt = p;
   pt.trace = tr.dev;
   hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, MASK3D>), dim3(p.B * p.H), dim3(512), lds, st, pt);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+template <int DH, bool MASK3D> int bwd_fused256_launch(const AttnP& p, hipStream_t st) {
+  const double work = (double)p.B * p.H * p.Tq * p.Tk * DH;
+  const double io = ((double)p.B * p.H * DH * 2.0) * (4.0 * p.Tq + 4.0 * p.Tk);
+  const int lds = 256 * DH * 2 + 2 * 64 * DH * 2 + 256 * 128 + 256 * 4 * 2 + 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused256_kernel<DH, MASK3D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  ImtProfScope prof("attn_bwd_fused256_bf16", 10.0 * work, io, st);
+  hipLaunchKernelGGL((attn_bwd_fused256_kernel<DH, MASK3D>), dim3(p.B * p.H), dim3(512), lds, st, p);
   IMT_CHECK_LAUNCH();
   return IMT_OK;
 }
@@ -853,6 +1079,11 @@ extern "C" int imt_attention_bwd(const imt_attn_args* a, void* stream) {
   if (a->Tq <= 128 && a->Tk <= 128 && idx32 && !getenv("IMT_ATTN_NO_FUSED_BWD")) {  // short sequences: one fused kernel
     if (p.mask3d) return a->head_dim == 32 ? bwd_fused_launch<32, true>(p, st) : bwd_fused_launch<64, true>(p, st);
     return a->head_dim == 32 ? bwd_fused_launch<32, false>(p, st) : bwd_fused_launch<64, false>(p, st);
+  }
+  // 129 .. 256 keys / queries (MASS: encoder self-attention at 256 tokens, the decoder's cross-attention over them)
+  if (a->Tq <= 256 && a->Tk <= 256 && idx32 && !getenv("IMT_ATTN_NO_FUSED_BWD") && !getenv("IMT_ATTN_NO_FUSED256")) {
+    if (p.mask3d) return a->head_dim == 32 ? bwd_fused256_launch<32, true>(p, st) : bwd_fused256_launch<64, true>(p, st);
+    return a->head_dim == 32 ? bwd_fused256_launch<32, false>(p, st) : bwd_fused256_launch<64, false>(p, st);
   }
   return a->head_dim == 32 ? bwd_launch<bf16_t, 32>(p, st) : bwd_launch<bf16_t, 64>(p, st);
 }

@@ -283,8 +283,9 @@ def test_c4_mass_bf16_parity_and_dispatch(c4):
         assert abs(float(loss.detach()) - loss_ref) <= 2e-2 * abs(loss_ref)
         _check_grads(ours, ref, 1e-1, 150, "C4 bf16", worst_tol=2.5e-1)
         # the 256-key attention path: encoder self-attention and the decoder's cross-attention take the tiled forward and the
-        # two-kernel backward (the fused single-workgroup backward is for <= 128 keys)
-        assert kinds.get("attn_bwd_dkdv_bf16", 0) >= 6 and kinds.get("attn_bwd_dq_bf16", 0) >= 6, kinds
+        # fused 256-key backward (round 3; rounds 1-2: the dQ + dK/dV kernel pair), the decoder's self-attention the 128-key one
+        assert kinds.get("attn_bwd_fused256_bf16", 0) >= 12 and kinds.get("attn_bwd_fused_bf16", 0) >= 6, kinds
+        assert "attn_bwd_dkdv_bf16" not in kinds and "attn_bwd_dq_bf16" not in kinds, kinds
         assert sum(v for k, v in kinds.items() if k.startswith("gemm_ws_bf16")) >= 20, kinds
         assert any(k.startswith("xent_fused") for k in kinds), kinds
     finally:

@@ -464,10 +464,13 @@ def test_attention_fwd_bwd(cuda, dtype, dh, case):
     assert_close(dv, vr.grad, tolb, "attn dv " + case)
 
 
-@pytest.mark.parametrize("dh,Tq,Tk,causal", [(64, 128, 128, False), (64, 127, 127, True), (32, 100, 128, False), (64, 128, 49, False)])
+@pytest.mark.parametrize("dh,Tq,Tk,causal", [(64, 128, 128, False), (64, 127, 127, True), (32, 100, 128, False), (64, 128, 49, False),
+                                             (64, 256, 256, False), (64, 255, 255, True), (64, 128, 256, False), (32, 200, 130, False),
+                                             (64, 130, 200, False), (32, 256, 256, True)])
 def test_attention_bwd_fused_matches_two_kernel_path(cuda, dh, Tq, Tk, causal):
-    """bf16, Tq/Tk <= 128: the single fused backward kernel against the dQ + dK/dV kernel pair on the same inputs,
-    with key padding, query mask, dropout (same counter-based mask) and strided q|k|v views."""
+    """bf16: the single fused backward kernel (Tq / Tk <= 128) and its 256-key sibling (129 .. 256: the MASS shapes of BASELINE
+    configs[4]) against the dQ + dK/dV kernel pair on the same inputs, with key padding, query mask, dropout (same
+    counter-based mask) and strided q|k|v views; the dispatch is asserted through the profiler kinds."""
     import os
     from imagetranslate_amd import hip_ops as O
     g = torch.Generator().manual_seed(9)
@@ -482,19 +485,34 @@ def test_attention_bwd_fused_matches_two_kernel_path(cuda, dh, Tq, Tk, causal):
     kw = dict(key_mask=kmask, query_mask=qmask, causal=causal, dropout_p=0.1, dropout_seed=4242)
     o, lse = O.attention_fwd(q, k, v, B, H, Tq, Tk, dh, **kw)
     do = torch.randn(B * Tq, d, generator=g).bfloat16().cuda()
-    res = {}
+    from imagetranslate_amd import _lib as L
+    lib = L.load()
+    res, kinds = {}, {}
     for name, env in (("fused", None), ("pair", "1")):
         if env is None:
             os.environ.pop("IMT_ATTN_NO_FUSED_BWD", None)
         else:
             os.environ["IMT_ATTN_NO_FUSED_BWD"] = env
         try:
+            torch.cuda.synchronize()
+            lib.imt_prof_enable(1)
             res[name] = [t.float().cpu() for t in O.attention_bwd(do, q, k, v, o, lse, B, H, Tq, Tk, dh, **kw)]
+            torch.cuda.synchronize()
+            rows = (L.ProfRow * 64)()
+            kinds[name] = {rows[i].kind.decode() for i in range(lib.imt_prof_report(rows, 64))}
         finally:
+            lib.imt_prof_enable(0)
             os.environ.pop("IMT_ATTN_NO_FUSED_BWD", None)
+    big = max(Tq, Tk) > 128
+    assert ("attn_bwd_fused256_bf16" if big else "attn_bwd_fused_bf16") in kinds["fused"], kinds
+    assert {"attn_bwd_dq_bf16", "attn_bwd_dkdv_bf16"} <= kinds["pair"], kinds
     for what, a, b in zip(("dQ", "dK", "dV"), res["fused"], res["pair"]):
         assert_close(a, b, 1e-2, "fused vs two-kernel " + what)
     assert torch.equal(res["fused"][2], res["pair"][2]), "dV follows the same operation order in both paths"
+    # same inputs, same launch: bit-identical (nothing is summed across workgroups)
+    again = [t.float().cpu() for t in O.attention_bwd(do, q, k, v, o, lse, B, H, Tq, Tk, dh, **kw)]
+    for a, b in zip(again, res["fused"]):
+        assert torch.equal(a, b)
 
 
 def test_attention_fused_qkv_views_and_dropout(cuda):
