@@ -38,6 +38,7 @@ class GemmArgs(Structure):
         ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
         ("ln_tickets", c_void_p),
         ("ln_eps", c_float), ("reserved_ln", c_int32),
+        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
     ]
 
 
@@ -158,6 +159,7 @@ SIGNATURES = {
     "imt_last_error": (c_char_p, []),
     "imt_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "imt_gemm_grouped_tn": (c_int, [POINTER(GemmArgs), c_int, _P]),
+    "imt_gemm_splitk_ws_bytes": (c_int64, []),
     "imt_gemm_bias_residual_ln_supported": (c_int, [c_int, c_int, c_int]),
     "imt_gemm_bias_residual_ln": (c_int, [c_int, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int,
                                           c_int, c_float, c_float, c_uint64, _P]),

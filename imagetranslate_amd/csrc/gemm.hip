@@ -145,7 +145,8 @@ struct EpiParams {
   float* a_colsum;  // TN only: a_colsum[m] += alpha * sum_k A[k][m]   (bias gradient fused into the dW GEMM)
   int dbg;          // tuning only (tools/gemm_shapes.py): bit0 skip the tile products, bit1 skip the in-loop DMA
   unsigned long long* trace;  // tuning only (IMT_TRACE=gemm_ws | gemm_xl): per-workgroup phase time stamps
-  int64_t slab_elems;         // 256-tile kernel, split-K slab mode: C of K split y = C + y * slab_elems (fp32 slabs)
+  int64_t slab_elems;         // split-K slab mode: C of K split y = C + y * slab_elems (fp32 slabs)
+  int splits = 1;             // persistent kernel, split-K slab mode: K ranges per output tile (imt_gemm_args.splitk_ws)
   // in-launch LayerNorm of finished row blocks (persistent kernel, one tile per workgroup; ln_rowblock_tail)
   const void* ln_gamma = nullptr; const void* ln_beta = nullptr; void* ln_out = nullptr; int64_t ld_ln = 0;
   float* ln_mean = nullptr; float* ln_rstd = nullptr; int* ln_tickets = nullptr; float ln_eps = 0.f;
@@ -802,38 +803,53 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* epi = smem + WS_NST * STAGE_BYTES;
   const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
-  const int tiles = nbx * nby;
+  // split-K slab mode (ep.splits > 1): a work item is (output tile, K range); items of one tile are neighbours in the XCD-affine
+  // order, so its slabs are written by one XCD.  Every range holds at least one K tile (host-checked).
+  const int S = ep.splits > 1 ? ep.splits : 1;
+  const int tiles = nbx * nby * S;
   // whole K tiles for NT / NN (host-checked).  TN (weight gradients: K = token count, any value): both operands are K-STRIDED,
   // so the rows of a ragged last K tile lie past the operands' valid bytes and the descriptors' range check fills them with
   // zeros -- they add nothing to the products (or to the fused column sums)
-  const int nt = (K + BK - 1) / BK;
+  const int nt_all = (K + BK - 1) / BK;
+  const int per = (nt_all + S - 1) / S;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool consumer = wave < 4;
   const int my_tiles = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const bool colsum_kernel = (LAYOUT == IMT_TN) && ep.a_colsum;
+  // work item i of this workgroup -> output tile lt, K range [kt0, kt0 + ntl) in K tiles, slab ks
+  const auto item = [&](int i, int& lt, int& kt0, int& ntl) {
+    const int v = imt_xcd_block(blockIdx.x + i * gridDim.x, tiles);
+    lt = v / S;
+    const int ks = v - lt * S;
+    kt0 = ks * per;
+    ntl = min(per, nt_all - kt0);
+    return ks;
+  };
 
   if (!consumer) {
     // ------------------------------------------------------------ producers: flat stream of (tile, k) steps
     Dma<T, A_KC> da; Dma<T, B_KC> db;
-    const int total = my_tiles * nt;
-    int iq = 0, tq = 0;  // tile / k index of the NEXT step to issue
-    int rot = 0;
+    int total = 0;
+    for (int i = 0; i < my_tiles; ++i) { int lt, kt0, ntl; item(i, lt, kt0, ntl); total += ntl; }
+    int iq = 0, tq = 0;  // item / k index of the NEXT step to issue
+    int rot = 0, nt_q = 0;
     auto issue_next = [&](int slot) {
       if (tq == 0) {
-        const int lt = imt_xcd_block(blockIdx.x + iq * gridDim.x, tiles);
-        da.init(A, lda, a_bytes, (lt / nbx) * BM, 0, wave - 4);
-        db.init(B, ldb, b_bytes, (lt % nbx) * BN, 0, wave - 4);
+        int lt, kt0;
+        item(iq, lt, kt0, nt_q);
+        da.init(A, lda, a_bytes, (lt / nbx) * BM, kt0 * BK, wave - 4);
+        db.init(B, ldb, b_bytes, (lt % nbx) * BN, kt0 * BK, wave - 4);
         // (experiment) the workgroups that share an operand row block start at different K tiles, so a tile is
         // fetched from the Infinity Cache by one of them and found in the XCD's L2 by the others
-        if (IMT_WS_ROTATE && sizeof(T) == 2) rot = ((lt % nbx) * nt / nbx + (lt / nbx)) % nt;
+        if (IMT_WS_ROTATE && sizeof(T) == 2 && S == 1) rot = ((lt % nbx) * nt_q / nbx + (lt / nbx)) % nt_q;
       }
       int tk = tq + rot;
-      if (tk >= nt) tk -= nt;
+      if (tk >= nt_q) tk -= nt_q;
       if (!(IMT_WS_ABLATE & 2)) {  // (-DIMT_WS_ABLATE=2: no DMA, the consumers multiply whatever the ring holds; 3: bare loop)
         da.issue(smem + slot * STAGE_BYTES, tk);
         db.issue(smem + slot * STAGE_BYTES + TILE_BYTES, tk);
       }
-      if (++tq == nt) { tq = 0; ++iq; }
+      if (++tq == nt_q) { tq = 0; ++iq; }
     };
     int issued = 0;
 #pragma unroll
@@ -850,27 +866,33 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       wait_newer(issued - 1);
       asm volatile("s_barrier" ::: "memory");
     }
+    int ci = 0, nt_c = 0;  // item being consumed and its K tiles
+    if (my_tiles > 0) { int lt, kt0; item(0, lt, kt0, nt_c); }
     for (int q = 0; q < total; ++q) {
       // steps issued after the step this barrier publishes (classic: step q; run-ahead: step q + 1)
       wait_newer(issued - 1 - q - (IMT_WS_RUNAHEAD ? 1 : 0));
       asm volatile("s_barrier" ::: "memory");
       if (issued < total) { issue_next(cur == 0 ? WS_NST - 1 : cur - 1); ++issued; }
       cur = (cur + 1 == WS_NST) ? 0 : cur + 1;
-      if (++t == nt) {
+      if (++t == nt_c) {
         t = 0;
         if (q == total - 1) {
           // last tile of this workgroup: nothing left to stream, so the producer waves take half of the epilogue's
           // group loop (with one tile per CU -- every N = 512 GEMM of the step -- the epilogue is fully exposed)
-          const int lt = imt_xcd_block(blockIdx.x + (my_tiles - 1) * gridDim.x, tiles);
+          int lt, kt0, ntl;
+          const int ks = item(my_tiles - 1, lt, kt0, ntl);
           const f32x4 none[4][4] = {};
           const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
-          epilogue<T, 512, false>(none, epi, (lt / nbx) * BM, (lt % nbx) * BN, -1, 0, M, N, ep, alpha);
+          EpiParams eps = ep;
+          if (S > 1) eps.C = reinterpret_cast<float*>(ep.C) + (int64_t)ks * ep.slab_elems;
+          epilogue<T, 512, false>(none, epi, (lt / nbx) * BM, (lt % nbx) * BN, -1, 0, M, N, eps, alpha);
           if (IMT_LN_TICKET && ep.ln_out) ln_rowblock_tail<T>(ep, epi, (lt / nbx) * BM, lt / nbx, nbx, M, N);  // (host: one tile per workgroup)
         } else {
           // the consumers' epilogue: 2 passes x 2 barriers
           asm volatile("s_barrier\n\ts_barrier\n\ts_barrier\n\ts_barrier" ::: "memory");
         }
         if (colsum_kernel) asm volatile("s_barrier\n\ts_barrier" ::: "memory");  // + the fused column sums
+        if (++ci < my_tiles) { int lt, kt0; item(ci, lt, kt0, nt_c); }
       }
     }
   } else {
@@ -879,9 +901,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
     const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
     int cur = 0;
     IMT_STAMP(ep.trace, 0);
-    if (IMT_WS_RUNAHEAD && my_tiles * nt > 0) asm volatile("s_barrier" ::: "memory");  // step 0 landed (same condition as the producers' total > 0)
+    if (IMT_WS_RUNAHEAD && my_tiles * nt_all > 0) asm volatile("s_barrier" ::: "memory");  // step 0 landed (same condition as the producers' total > 0; run-ahead builds: no split-K)
     for (int i = 0; i < my_tiles; ++i) {
-      const int lt = imt_xcd_block(blockIdx.x + i * gridDim.x, tiles);
+      int lt, kt0, nt;
+      const int ks = item(i, lt, kt0, nt);
       const int m0 = (lt / nbx) * BM, n0 = (lt % nbx) * BN;
       f32x4 acc[4][4];
 #pragma unroll
@@ -930,10 +953,12 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(const T* __restrict
       }
 #endif
       if (i == 0) IMT_STAMP(ep.trace, 2);
+      EpiParams eps = ep;
+      if (S > 1) eps.C = reinterpret_cast<float*>(ep.C) + (int64_t)ks * ep.slab_elems;
       if (i == my_tiles - 1) {
-        epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);  // producers join in
+        epilogue<T, 512, true>(acc, epi, m0, n0, wm, wn, M, N, eps, alpha);  // producers join in
         if (IMT_LN_TICKET && ep.ln_out) ln_rowblock_tail<T>(ep, epi, m0, lt / nbx, nbx, M, N);
-      } else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, ep, alpha);
+      } else epilogue<T>(acc, epi, m0, n0, wm, wn, M, N, eps, alpha);
       if (i == 0) IMT_STAMP(ep.trace, 3);
       if (i == my_tiles - 1) IMT_STAMP(ep.trace, 4);
       if (colsum_kernel) cs.flush(epi, ep.a_colsum, m0, M, alpha, do_colsum);
@@ -1420,7 +1445,7 @@ int launch(const imt_gemm_args* a, const EpiParams& ep, int splits, int k_per_sp
     if (!ws_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kws), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS); ws_attr = true; }
     const int64_t a_bytes = (LAYOUT == IMT_TN) ? view_bytes(a->K, a->lda, a->M, sizeof(T)) : view_bytes(a->M, a->lda, a->K, sizeof(T));
     const int64_t b_bytes = (LAYOUT == IMT_NT) ? view_bytes(a->N, a->ldb, a->K, sizeof(T)) : view_bytes(a->K, a->ldb, a->N, sizeof(T));
-    const int tiles = nbx * nby;
+    const int tiles = nbx * nby * (ep.splits > 1 ? ep.splits : 1);
     ImtTrace tr("gemm_ws", tiles < 256 ? tiles : 256, st);
     EpiParams ept = ep;
     ept.trace = tr.dev;
@@ -1467,7 +1492,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   Vec4<TC>::store(c, v);
 }
 
+// Split-K slab mode of the persistent kernel (imt_gemm_args.splitk_ws): C = epilogue(alpha * sum_s slab[s]) -- the slabs are
+// summed in split order whatever order they were written in, then bias / GELU (aux <- pre-activation) / GELU' (aux) /
+// dropout (element index m * N + n, as the GEMM epilogues) / residual / accumulate, C of the operand type or fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ slabs, int64_t slab_elems, int splits, int M, int N,
+                                                              EpiParams ep) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 4-column group index (N % 4 == 0)
+  const int n4 = N >> 2;
+  if (q >= (int64_t)M * n4) return;
+  const int m = (int)(q / n4), n = (int)(q % n4) * 4;
+  f32x4 v = Vec4<float>::load(slabs + (int64_t)m * N + n);
+  for (int sidx = 1; sidx < splits; ++sidx) v += Vec4<float>::load(slabs + sidx * slab_elems + (int64_t)m * N + n);
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+  v *= alpha;
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  const T* resid = reinterpret_cast<const T*>(ep.resid);
+  T* aux = reinterpret_cast<T*>(ep.aux);
+  if (bias) v += Vec4<T>::load(bias + n);
+  if (ep.aux_mode == IMT_AUX_GELU_FWD) {
+    Vec4<T>::store(aux + (int64_t)m * ep.ldaux + n, v);
+    v = gelu_erf4(v);
+  } else if (ep.aux_mode == IMT_AUX_DGELU) {
+    v *= gelu_erf_grad4(Vec4<T>::load(aux + (int64_t)m * ep.ldaux + n));
+  }
+  if (ep.drop_thresh) dropout_apply4(v, ep.seed, (uint64_t)m * (uint64_t)N + (uint64_t)n, ep.drop_thresh, ep.inv_keep);
+  if (resid) v += Vec4<T>::load(resid + (int64_t)m * ep.ldr + n);
+  if (ep.c_f32) {
+    float* c = reinterpret_cast<float*>(ep.C) + (int64_t)m * ep.ldc + n;
+    if (ep.accumulate) v += Vec4<float>::load(c);
+    Vec4<float>::store(c, v);
+  } else {
+    T* c = reinterpret_cast<T*>(ep.C) + (int64_t)m * ep.ldc + n;
+    if (ep.accumulate) v += Vec4<T>::load(c);
+    Vec4<T>::store(c, v);
+  }
+}
+
+// how many K ranges for a product with `tiles` output tiles of 128 x 128 and `nt` K tiles; 1 = do not split
+int splitk_choice(int64_t tiles, int nt) {
+  static const int off = getenv("IMT_GEMM_NO_SMALL_SPLITK") ? 1 : 0;  // tuning / tests
+  if (off || tiles > 128 || nt < 16) return 1;
+  int s = (int)(256 / tiles);
+  if (s > 8) s = 8;
+  if (s > nt / 4) s = nt / 4;  // at least four K tiles per range: below that the ramp of a range costs more than it saves
+  if (s < 2) return 1;
+  const int per = (nt + s - 1) / s;
+  return (nt + per - 1) / per;  // every range non-empty
+}
+
 }  // namespace
+
+extern "C" int64_t imt_gemm_splitk_ws_bytes(void) { return (int64_t)256 * BM * BN * 4 + 4096; }
 
 // aux_mode IMT_AUX_SPLITK_WS: a product with few output tiles and a very long K (dX through the vocabulary: 8128 x 512 x
 // 30000 has 64 tiles of 256 x 256) runs as split_k K-ranges of 256-tile workgroups, each into its own fp32 slab of the
@@ -1599,6 +1675,48 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
     if (rc != IMT_OK || !a->ln_out) return rc;
     return imt_layernorm_fwd(a->dtype, a->C, a->ln_gamma, a->ln_beta, a->ln_out, a->ln_mean, a->ln_rstd, a->M, a->N, a->ln_eps, 0.f, 0, stream);
   }
+  // few output tiles, long K, a workspace for partial sums: K ranges on the persistent kernel + one epilogue launch
+  if (a->force_general == 0 && a->splitk_ws && splits == 1 && a->layout != IMT_TN && pipe_ok && a->N % 4 == 0 && !a->a_colsum) {
+    const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
+    const int S = splitk_choice(tiles, a->K / bk);
+    const int64_t rows_pad = (int64_t)imt_cdiv(a->M, BM) * BM;  // edge tiles store only rows < M, slabs are addressed [m][n] with ld N
+    if (S > 1 && (int64_t)S * a->M * a->N * 4 <= a->splitk_ws_bytes && rows_pad > 0 && ((uintptr_t)a->splitk_ws & 15) == 0) {
+      if (a->aux_mode != IMT_AUX_NONE) IMT_CHECK_ARG(a->aux != nullptr, "imt_gemm: aux_mode needs aux");
+      if (a->ln_out) {
+        IMT_CHECK_ARG(a->ln_gamma && a->ln_beta, "imt_gemm: ln_out needs ln_gamma and ln_beta");
+        IMT_CHECK_ARG(a->c_dtype == a->dtype && !a->accumulate && a->ldc == a->N && a->ld_ln == a->N, "imt_gemm: ln_out needs contiguous C of the compute type");
+      }
+      hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+      EpiParams slab;
+      slab.C = a->splitk_ws; slab.ldc = a->N; slab.c_f32 = 1; slab.accumulate = 0;
+      slab.bias = nullptr; slab.resid = nullptr; slab.ldr = 0; slab.aux = nullptr; slab.ldaux = 0; slab.aux_mode = IMT_AUX_NONE;
+      slab.atomic = 0; slab.alpha = 1.0f; slab.alpha_dev = nullptr; slab.inv_keep = 1.0f; slab.drop_thresh = 0; slab.seed = 0;
+      slab.a_colsum = nullptr; slab.dbg = 0; slab.trace = nullptr;
+      slab.slab_elems = (int64_t)a->M * a->N; slab.splits = S;
+      int rc = (a->dtype == IMT_F32) ? dispatch<float>(a, slab, 1, a->K, 5, st) : dispatch<bf16_t>(a, slab, 1, a->K, 5, st);
+      if (rc != IMT_OK) return rc;
+      EpiParams ep;
+      ep.C = a->C; ep.ldc = a->ldc; ep.c_f32 = c_f32; ep.accumulate = a->accumulate;
+      ep.bias = a->bias; ep.resid = a->resid; ep.ldr = a->ldr;
+      ep.aux = a->aux; ep.ldaux = a->ldaux; ep.aux_mode = a->aux_mode; ep.atomic = 0;
+      ep.alpha = a->alpha; ep.alpha_dev = a->alpha_dev;
+      ep.drop_thresh = dropout_thresh(a->dropout_p);
+      ep.inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
+      ep.seed = a->dropout_seed; ep.a_colsum = nullptr; ep.dbg = 0; ep.trace = nullptr; ep.slab_elems = 0;
+      {
+        const int64_t groups = (int64_t)a->M * (a->N / 4);
+        ImtProfScope prof("gemm_splitk_epilogue", 0.0, (double)a->M * a->N * (4.0 * S + 2.0 * es), st);
+        const float* slabs = reinterpret_cast<const float*>(a->splitk_ws);
+        if (a->dtype == IMT_F32)
+          hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(imt_cdiv(groups, 256)), dim3(256), 0, st, slabs, slab.slab_elems, S, a->M, a->N, ep);
+        else
+          hipLaunchKernelGGL(splitk_epilogue_kernel<bf16_t>, dim3(imt_cdiv(groups, 256)), dim3(256), 0, st, slabs, slab.slab_elems, S, a->M, a->N, ep);
+        IMT_CHECK_LAUNCH();
+      }
+      if (!a->ln_out) return IMT_OK;
+      return imt_layernorm_fwd(a->dtype, a->C, a->ln_gamma, a->ln_beta, a->ln_out, a->ln_mean, a->ln_rstd, a->M, a->N, a->ln_eps, 0.f, 0, stream);
+    }
+  }
   const int64_t nblocks = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN) * splits;
   // kernel variant: 1 = register-staged double buffer (2 blocks/CU), 2 = LDS-DMA 3-stage ring (1 block/CU),
   // 3 = single buffer + register prefetch (4 blocks/CU).  a->force_general carries a variant code for tests/tuning.
@@ -1612,7 +1730,9 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   // still better served by three single-buffer blocks per CU overlapping each other's epilogues.
   if (variant == 0) {
     const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
-    if (pipe_ok && splits == 1 && (tiles <= 256 || a->K >= 1024)) variant = 5;
+    // (weight gradients with many output tiles and a short K -- few tokens: captioning, decoding-sized batches -- also run
+    // best on the persistent kernel: 30000 x 512 x 992 TN 64 against 92 us on the register-staged one, tools/tn_small_k.py)
+    if (pipe_ok && splits == 1 && (tiles <= 256 || a->K >= 1024 || a->layout == IMT_TN)) variant = 5;
     else variant = (a->layout == IMT_TN) ? 1 : 3;
     // 256 x 256 tiles (profiles/r01_gemm_xl_study.txt): several rounds of short-K tiles (vocabulary projection 797 vs 681
     // TFLOP/s, batched cross K/V), or one round whose epilogue touches a second matrix (GELU / GELU' / residual: 500 vs 430)

@@ -63,6 +63,8 @@ struct StackWs {
   float* ln_site(int site, int d) const { return ln_partial + (int64_t)site * IMT_LN_BWD_WS_FLOATS(d); }
   int32_t* ln_tickets;               // [ceil(N / 128)] row-block tickets of imt_gemm's in-launch LayerNorm (zero between launches)
   int64_t ln_ticket_bytes;
+  void* splitk; int64_t splitk_bytes; // fp32 slabs of imt_gemm's split-K mode (few output tiles: captioning / short batches); one
+                                     // product at a time on the main stream, the grouped weight gradients never use it
   int64_t bytes;
 };
 
@@ -134,12 +136,16 @@ void carve(const imt_stack_desc* m, int B, int T, int Tk, void* ws, StackWs& w, 
   w.ln_partial = (float*)c.take((int64_t)(3 * m->n_layers + 1) * IMT_LN_BWD_WS_FLOATS(d) * 4);
   w.ln_ticket_bytes = ((N + 127) / 128 + 1) * 4;
   w.ln_tickets = (int32_t*)c.take(w.ln_ticket_bytes);
+  // split-K slabs: only batches whose products have <= 128 output tiles can take that path (imt_gemm: splitk_choice)
+  w.splitk_bytes = ((N + 127) / 128) * ((d + 127) / 128) <= 128 ? imt_gemm_splitk_ws_bytes() : 0;
+  w.splitk = w.splitk_bytes ? c.take(w.splitk_bytes) : nullptr;
   w.bytes = c.off;
 }
 
 struct Ctx {
   const imt_stack_desc* m; hipStream_t st; int dtype; int64_t es;
   int32_t* ln_tickets = nullptr;  // zeroed row-block tickets (imt_stack_forward); null: dense + LayerNorm as two launches
+  void* splitk = nullptr; int64_t splitk_bytes = 0;  // imt_gemm_args.splitk_ws of every main-stream product
   const char* P(int64_t off) const { return reinterpret_cast<const char*>(m->params) + off * es; }
   float* G(int64_t off) const { return m->grads + off; }
 };
@@ -156,6 +162,7 @@ int linear_fwd(const Ctx& c, const void* x, int64_t ldx, int M, int K, int64_t w
   a.bias = b_off >= 0 ? c.P(b_off) : nullptr;
   a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = N; a.aux_mode = aux_mode; a.split_k = 1; a.alpha = 1.f;
   a.dropout_p = drop_p; a.dropout_seed = seed;
+  a.splitk_ws = c.splitk; a.splitk_ws_bytes = c.splitk_bytes;
   return imt_gemm(&a, c.st);
 }
 
@@ -168,6 +175,7 @@ int linear_bwd_input(const Ctx& c, const void* dy, int64_t lddy, int M, int N, i
   a.A = dy; a.lda = lddy; a.B = c.P(w_off); a.ldb = K; a.C = dx; a.ldc = lddx; a.c_dtype = c.dtype;
   a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = K; a.aux_mode = aux_mode; a.split_k = 1; a.alpha = 1.f;
   a.accumulate = accumulate;
+  a.splitk_ws = c.splitk; a.splitk_ws_bytes = c.splitk_bytes;
   return imt_gemm(&a, c.st);
 }
 
@@ -199,6 +207,7 @@ int dense_resid_ln(const Ctx& c, const void* x, int64_t ldx, int M, int K, int64
   a.dropout_p = drop_p; a.dropout_seed = seed;
   a.ln_gamma = c.P(g_off); a.ln_beta = c.P(beta_off); a.ln_out = out; a.ld_ln = N; a.ln_mean = mean; a.ln_rstd = rstd;
   a.ln_eps = c.m->ln_eps; a.ln_tickets = c.ln_tickets;
+  a.splitk_ws = c.splitk; a.splitk_ws_bytes = c.splitk_bytes;
   return imt_gemm(&a, c.st);
 }
 
@@ -391,6 +400,7 @@ extern "C" int imt_stack_forward(const imt_stack_desc* m, const imt_stack_io* io
   StackWs w; LayerWs layers[MAX_LAYERS];
   RC(validate(m, io, ws, ws_bytes, w, layers));
   Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  c.splitk = w.splitk; c.splitk_bytes = w.splitk_bytes;
   const int B = io->B, T = io->T, N = B * T, d = m->d;
   const bool training = io->training != 0;
   const uint64_t seed = io->dropout_seed;
@@ -443,6 +453,7 @@ extern "C" int imt_stack_backward(const imt_stack_desc* m, const imt_stack_io* i
   IMT_CHECK_ARG(m->grads && io->d_out, "stack_backward: grads / d_out missing");
   IMT_CHECK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= m->n_layers, "stack_backward: bad layer range");
   Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  c.splitk = w.splitk; c.splitk_bytes = w.splitk_bytes;
   const int B = io->B, T = io->T, N = B * T, d = m->d;
   const bool training = io->training != 0;
   const uint64_t seed = io->dropout_seed;
@@ -541,6 +552,7 @@ namespace {
 
 struct DecodeWs {
   void* emb_sum; void* x; void* ctx; void* pre_ln; void* a; void* q; void* b; void* h; void* z; float* mean; float* rstd;
+  void* splitk; int64_t splitk_bytes;  // imt_gemm's split-K slabs (R rows: a handful of output tiles per product)
   int64_t bytes;
 };
 
@@ -551,6 +563,8 @@ void carve_decode(const imt_stack_desc* m, int r_max, void* ws, DecodeWs& w) {
   w.a = c.take(R * d * es); w.q = c.take(R * d * es); w.b = c.take(R * d * es);
   w.h = c.take(R * ff * es); w.z = c.take(R * ff * es);
   w.mean = (float*)c.take(R * 4); w.rstd = (float*)c.take(R * 4);
+  w.splitk_bytes = imt_gemm_splitk_ws_bytes();
+  w.splitk = c.take(w.splitk_bytes);
   w.bytes = c.off;
 }
 
@@ -611,6 +625,7 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
   IMT_CHECK_ARG(ws && ws_bytes >= w.bytes, "decode_step: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
   IMT_CHECK_ARG(((uintptr_t)ws & 255) == 0, "decode_step: workspace must be 256-B aligned");
   Ctx c{m, (hipStream_t)stream, m->dtype, esize(m->dtype)};
+  c.splitk = w.splitk; c.splitk_bytes = w.splitk_bytes;
   const int R = io->R, d = m->d, ff = m->ff, H = m->heads, dh = d / H;
   const int64_t row3 = (int64_t)io->t_max * 3 * d;                       // one cache row (all positions)
   const int64_t self_layer = (int64_t)io->r_max * row3;

@@ -61,8 +61,9 @@ def _rowmajor(t):
 
 def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=None, aux_mode=IMT_AUX_NONE,
          accumulate=False, split_k=1, alpha=1.0, dropout_p=0.0, dropout_seed=0, alpha_dev=None, a_colsum=None,
-         force_general=False, force_pipeline=False, ln=None, _launch=True):
-    """C = epilogue(op(A) op(B)); see include/imt_hip.h:imt_gemm."""
+         force_general=False, force_pipeline=False, ln=None, splitk_ws=None, _launch=True):
+    """C = epilogue(op(A) op(B)); see include/imt_hip.h:imt_gemm.  ``splitk_ws``: fp32 scratch (``splitk_workspace(device)``)
+    that lets a product with few output tiles and a long K run as K ranges + one epilogue launch."""
     _req_cuda(A, B, out, bias, resid, aux)
     if layout == IMT_NT:
         M, K = A.shape; N = B.shape[0]; assert B.shape[1] == K
@@ -90,6 +91,9 @@ def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=N
     a.a_colsum = a_colsum.data_ptr() if a_colsum is not None else None
     a.force_general = int(force_general)
     a.force_pipeline = int(force_pipeline)
+    if splitk_ws is not None:
+        _req_cuda(splitk_ws)
+        a.splitk_ws, a.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     if ln is not None:
         # ln = dict(gamma, beta, out, mean, rstd, tickets (int32, zero), eps): LayerNorm of the rows of `out` in the same call
         _req_cuda(ln["gamma"], ln["beta"], ln["out"], ln["mean"], ln["rstd"], ln["tickets"])
@@ -102,6 +106,19 @@ def gemm(A, B, layout, *, out=None, out_dtype=None, bias=None, resid=None, aux=N
         return a
     L.check(L.load().imt_gemm(ctypes.byref(a), _stream()), "imt_gemm")
     return out
+
+
+_SPLITK_WS = {}
+
+
+def splitk_workspace(device):
+    """One fp32 scratch per device for imt_gemm's split-K slab mode (stream-ordered use: one product at a time)."""
+    key = (device.type, device.index)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = torch.empty(int(L.load().imt_gemm_splitk_ws_bytes()) // 4, device=device, dtype=torch.float32)
+        _SPLITK_WS[key] = ws
+    return ws
 
 
 def gemm_grouped_tn(problems):

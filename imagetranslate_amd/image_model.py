@@ -38,7 +38,7 @@ class _ImageHeadFn(torch.autograd.Function):
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         xd = O.add_rows_dropout(x.reshape(B * R, C).contiguous(), None, out_dtype=dtype, dropout_p=p, dropout_seed=seed)
-        y = O.gemm(xd, w, O.IMT_NT)
+        y = O.gemm(xd, w, O.IMT_NT, splitk_ws=O.splitk_workspace(xd.device))
         out = O.add_rows_dropout(y, loc, dropout_p=p, dropout_seed=seed + 1)
         ctx.store, ctx.wo, ctx.lo, ctx.dims, ctx.p, ctx.seed = store, wo, lo, (B, R, d, C), p, seed
         ctx.save_for_backward(xd)

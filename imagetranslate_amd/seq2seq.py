@@ -107,7 +107,7 @@ class _FusedXentFn(torch.autograd.Function):
             dx = O.alloc_rows(n, K, dlogits.dtype, dlogits.device)
             O.gemm(dlogits, w, O.IMT_NN, out=dx, aux=slabs, aux_mode=O.IMT_AUX_SPLITK_WS, split_k=splits, alpha_dev=g)
         else:
-            dx = O.gemm(dlogits, w, O.IMT_NN, alpha_dev=g)
+            dx = O.gemm(dlogits, w, O.IMT_NN, alpha_dev=g, splitk_ws=O.splitk_workspace(dlogits.device))  # few rows: K ranges (imt_gemm)
         gw = store.grad[ctx.wo:ctx.wo + V * K].view(V, K)
         sk = max(1, min(n // 512, 512 // max(1, ((V + 127) // 128) * ((K + 127) // 128))))
         O.gemm(dlogits, x, O.IMT_TN, out=gw, accumulate=(sk == 1), split_k=sk, alpha_dev=g,

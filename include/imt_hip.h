@@ -130,7 +130,16 @@ typedef struct imt_gemm_args {
   int32_t* ln_tickets;
   float ln_eps;
   int32_t reserved_ln;
+  /* Few output tiles and a long K (the reference's inference and captioning callers: src/seq_gen.py:164-194 decodes
+   * batch x beam = 320 rows per step, src/train_captioning.py:51-72 trains on 32 x 31 caption tokens; 128-row tiles then
+   * occupy 12-52 of the 256 CUs and each walks the whole K alone).  With a caller-owned fp32 workspace here, imt_gemm may run
+   * such a product (NT / NN, K >= 16 tiles) as 2..8 K-ranges per output tile on the persistent kernel, each range into its own
+   * fp32 slab, followed by ONE launch that sums the slabs in a fixed order and applies the whole epilogue (bias, GELU /
+   * GELU' with aux, dropout, residual, accumulate, C of either type): no atomics, bit-reproducible.  NULL / too small: never
+   * taken.  imt_gemm_splitk_ws_bytes() is enough for every product whose 128 x 128 tiles times splits stay <= 256. */
+  void* splitk_ws; int64_t splitk_ws_bytes;
 } imt_gemm_args;
+int64_t imt_gemm_splitk_ws_bytes(void);
 int imt_gemm(const imt_gemm_args* a, void* stream);
 /* All weight-gradient GEMMs (IMT_TN, fp32 C += alpha * A^T B, optional a_colsum) of one transformer layer in ONE
  * launch (HOST array of `count` descriptors).  Problems that cannot be grouped fall back to imt_gemm each. */

@@ -813,3 +813,95 @@ def test_gemm_with_layernorm_of_finished_rows(cuda, dtype, shape):
             assert_close(y.float(), ref_y.float(), 1e-5 if dtype == torch.float32 else 8e-3, "in-launch LayerNorm vs the two-launch path")
             assert_close(mean, ref_c.float().mean(1), 1e-5 if dtype == torch.float32 else 1e-4, "row means")
             assert_close(rstd, 1.0 / torch.sqrt(ref_c.float().var(1, unbiased=False) + 1e-12), 1e-4, "row rstd")
+
+
+# ------------------------------------------------------------------------------------------------ split-K for few output tiles
+def _kinds(fn):
+    from imagetranslate_amd import _lib as L
+    lib = L.load()
+    torch.cuda.synchronize()
+    lib.imt_prof_enable(1)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        rows = (L.ProfRow * 64)()
+        kinds = {rows[i].kind.decode(): int(rows[i].launches) for i in range(lib.imt_prof_report(rows, 64))}
+    finally:
+        lib.imt_prof_enable(0)
+    return out, kinds
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_small_m_split_k_with_epilogues(cuda, dtype, layout):
+    """Few output tiles and a long K (decoding: batch x beam = 320 rows, src/seq_gen.py:164-194; captioning: 32 x 31 caption
+    tokens, src/train_captioning.py:51-72): with a workspace, imt_gemm runs K ranges on the persistent kernel + one epilogue
+    launch.  Every epilogue the runtime uses, against the unsplit product (summation order differs: tolerance) and the fp32
+    reference; two runs bit-identical (fixed summation order, no atomics); dispatch asserted through the profiler kinds."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(31)
+    bk = 64 if dtype == torch.bfloat16 else 32
+    tol = 3e-5 if dtype == torch.float32 else 1.5e-2
+    ws = O.splitk_workspace(cuda)
+    for (M, N, nk, expect_split) in [(320, 512, 32, True), (992, 512, 32, True), (1000, 264, 24, True), (61, 128, 16, True),
+                                     (320, 512, 8, False), (4224, 512, 32, False)]:
+        K = nk * bk
+        A, Af = _mk((M, K), dtype, cuda, 0.5, g)
+        B, Bf = _mk((N, K) if layout == O.IMT_NT else (K, N), dtype, cuda, 0.2, g)
+        bias, biasf = _mk((N,), dtype, cuda, 1.0, g)
+        R, Rf = _mk((M, N), dtype, cuda, 1.0, g)
+        base = Af @ (Bf.t() if layout == O.IMT_NT else Bf)
+        out, kinds = _kinds(lambda: O.gemm(A, B, layout, bias=bias, splitk_ws=ws))
+        assert ("gemm_splitk_epilogue" in kinds) == expect_split, (M, N, K, kinds)
+        assert_close(out, base + biasf, tol, "split-K bias")
+        if not expect_split:
+            assert torch.equal(out, O.gemm(A, B, layout, bias=bias)), "without a split the workspace must change nothing"
+            continue
+        assert_close(out, O.gemm(A, B, layout, bias=bias), tol, "split vs unsplit")
+        assert torch.equal(out, O.gemm(A, B, layout, bias=bias, splitk_ws=ws)), "fixed summation order"
+        # GELU (pre-activation saved), GELU', dropout + residual, accumulate into fp32 and into the operand type
+        aux = torch.empty((M, N), device=cuda, dtype=dtype)
+        h = O.gemm(A, B, layout, bias=bias, aux=aux, aux_mode=O.IMT_AUX_GELU_FWD, splitk_ws=ws)
+        assert_close(aux, base + biasf, tol, "split-K gelu aux")
+        assert_close(h, F.gelu(base + biasf), tol, "split-K gelu")
+        z = (base + biasf).to(dtype).float().requires_grad_(True)
+        F.gelu(z).sum().backward()
+        assert_close(O.gemm(A, B, layout, aux=aux, aux_mode=O.IMT_AUX_DGELU, splitk_ws=ws), base * z.grad, 2 * tol, "split-K dgelu")
+        d1 = O.gemm(A, B, layout, bias=bias, resid=R, dropout_p=0.2, dropout_seed=99, splitk_ws=ws).float().cpu()
+        d0 = O.gemm(A, B, layout, bias=bias, resid=R, dropout_p=0.2, dropout_seed=99).float().cpu()
+        assert_close(d1, d0, tol, "split-K dropout + residual (same mask as the GEMM epilogue)")
+        assert float(((d1 - Rf) == 0).float().mean()) == pytest.approx(0.2, abs=0.03)
+        C0 = torch.randn((M, N), generator=g)
+        C = C0.clone().to(cuda)
+        O.gemm(A, B, layout, out=C, accumulate=True, alpha=0.5, splitk_ws=ws)
+        assert_close(C, C0 + 0.5 * base, tol, "split-K alpha + accumulate f32")
+        Ct, Ctf = _mk((M, N), dtype, cuda, 1.0, g)
+        O.gemm(A, B, layout, out=Ct, accumulate=True, splitk_ws=ws)
+        assert_close(Ct, Ctf + base, 2 * tol, "split-K accumulate")
+        # strided C (the decode step writes q|k|v of the new position into a cache row) and strided A
+        wide = torch.zeros((M, 3 * N), device=cuda, dtype=dtype)
+        O.gemm(A, B, layout, out=wide[:, N:2 * N], bias=bias, splitk_ws=ws)
+        assert_close(wide[:, N:2 * N], base + biasf, tol, "split-K strided C")
+        assert float(wide[:, :N].abs().max()) == 0 and float(wide[:, 2 * N:].abs().max()) == 0
+        # LayerNorm of the finished rows behind the split product
+        gam, gamf = _mk((N,), dtype, cuda, 1.0, g)
+        bet, betf = _mk((N,), dtype, cuda, 1.0, g)
+        ln = dict(gamma=gam, beta=bet, out=torch.empty((M, N), device=cuda, dtype=dtype), mean=torch.empty(M, device=cuda),
+                  rstd=torch.empty(M, device=cuda), tickets=torch.zeros((M + 127) // 128 + 1, dtype=torch.int32, device=cuda))
+        pre = O.gemm(A, B, layout, bias=bias, resid=R, ln=ln, splitk_ws=ws)
+        ref_ln = F.layer_norm(pre.float().cpu(), (N,), gamf, betf, 1e-12)
+        assert_close(ln["out"], ref_ln, 4 * tol if dtype == torch.float32 else 3e-2, "split-K + LayerNorm")
+
+
+def test_gemm_split_k_long_ragged_k(cuda):
+    """dX through the vocabulary with few rows (captioning: 992 x 512 x 30000): the ragged tail + whole-tile body split of
+    imt_gemm, the body on K ranges, scaled by a device scalar."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(32)
+    M, N, K = 992, 512, 30000
+    A, Af = _mk((M, K), torch.bfloat16, cuda, 0.05, g)
+    B, Bf = _mk((K, N), torch.bfloat16, cuda, 0.2, g)
+    gdev = torch.full((1,), 0.5, device=cuda)
+    out, kinds = _kinds(lambda: O.gemm(A, B, O.IMT_NN, alpha_dev=gdev, splitk_ws=O.splitk_workspace(cuda)))
+    assert "gemm_splitk_epilogue" in kinds, kinds
+    assert_close(out, 0.5 * (Af @ Bf), 1.5e-2, "ragged K + split-K")
