@@ -29,6 +29,8 @@
 * marshal_kat/  : the REFERENCE's own src/create_mt_batches.py ``write()`` (imported) on a 50-line parallel corpus and on
                   the monolingual source side, with a tokenizer its own src/textprocessor.py trains and re-loads:
                   corpus, tokenizer files (vocab.json / merges.txt / langs) and the two marshal files it wrote.
+* sample_enfa/   : the first 400 line pairs of the REFERENCE's own toy corpus src/sample/en.txt / fa.txt (BASELINE configs[0]: "MT on
+                  sample/ en<->fa toy pairs"), data only -- what README.md:167 tells a user to smoke-test on.
 * options_kat.json: every option of the REFERENCE's own src/option_parser.py parsers (flag strings, dest, type, action,
                   default), read from the parser objects it builds.
 """
@@ -299,6 +301,18 @@ def make_marshal_kat():
     print("marshal_kat:", len(ex), "parallel,", len(mono), "monolingual examples; vocab", tp.tokenizer.get_vocab_size())
 
 
+def make_sample_excerpt(n=400):
+    out = os.path.join(HERE, "sample_enfa")
+    os.makedirs(out, exist_ok=True)
+    for lang in ("en", "fa"):
+        with open("/root/reference/src/sample/%s.txt" % lang, "r", encoding="utf-8") as fr, open(os.path.join(out, lang + ".txt"), "w", encoding="utf-8") as fw:
+            for i, line in enumerate(fr):
+                if i >= n:
+                    break
+                fw.write(line)
+    print("sample_enfa:", {f: os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)})
+
+
 def make_options_kat():
     sys.path.insert(0, "/root/reference/src")
     import option_parser as ref_op
@@ -325,4 +339,5 @@ if __name__ == "__main__":
     make_beam_step1_kat()
     make_marshal_kat()
     make_options_kat()
+    make_sample_excerpt()
     print("wrote", os.listdir(HERE))

@@ -156,3 +156,58 @@ def test_captioning_train_and_caption_cli(cuda, tmp_path, capsys):
     hit = sum(len(set(by_path[paths[i]].split()) & set(class_caps[labels[i]].split())) / max(1, len(set(class_caps[labels[i]].split())))
               for i in range(n_img)) / n_img
     assert hit > 0.3, "captions should reproduce a good share of the class sentences' words (got %.2f)" % hit
+
+
+def test_config0_sample_corpus_against_oracle(cuda, tmp_path):
+    """BASELINE configs[0]: "MT on sample/ en<->fa toy pairs, 2-layer d=128 seq_len=32 batch=8" -- on the reference's own toy
+    corpus (tests/golden/sample_enfa/: the first 400 line pairs of src/sample/{en,fa}.txt, README.md:167's smoke data): BPE
+    tokenizer (vocabulary 1000, README.md:147), create_mt_batches, capacity batching, then five train steps (forward, smoothed
+    NLL, backward, clip, Adam with the inverse-sqrt schedule) of the HIP path in fp32 against the CPU oracle on the same
+    weights and batches: per-step losses within 1e-4, an updated weight within 1e-4, and the loss falls."""
+    from imagetranslate_amd import create_mt_batches, train_tokenizer
+    from imagetranslate_amd.dataset import MTDataset
+    from imagetranslate_amd.parallel import train_step
+    from imagetranslate_amd.seq2seq import Seq2Seq
+    from imagetranslate_amd.textprocessor import TextProcessor
+    from imagetranslate_amd.utils import AdamInverseSqrtWithWarmup
+    from oracle import reference_model as R
+    gold = os.path.join(os.path.dirname(__file__), "golden", "sample_enfa")
+    d = str(tmp_path)
+    en = [ln.strip() for ln in open(os.path.join(gold, "en.txt"), encoding="utf-8")]
+    fa = [ln.strip() for ln in open(os.path.join(gold, "fa.txt"), encoding="utf-8")]
+    assert len(en) == len(fa) == 400
+    with open(os.path.join(d, "all.txt"), "w", encoding="utf-8") as fw:
+        fw.write("\n".join(["<en> " + s + " </s>" for s in en if s] + ["<fa> " + t + " </s>" for t in fa if t]) + "\n")
+    tok = os.path.join(d, "tok")
+    train_tokenizer.main(["--data", os.path.join(d, "all.txt"), "--vocab_size", "1000", "--model", tok])
+    tp = TextProcessor(tok)
+    assert tp.languages == {"<en>": 0, "<fa>": 1} and 600 <= tp.vocab_size() <= 1000
+    create_mt_batches.main(["--src", os.path.join(gold, "en.txt"), "--dst", os.path.join(gold, "fa.txt"), "--src-lang", "en", "--dst-lang", "fa",
+                            "--tok", tok, "--output", os.path.join(d, "train.batch"), "--max_seq_len", "32", "--min_seq_len", "3"])
+    data = MTDataset(max_batch_capacity=600, max_batch=8 * 64, pad_idx=tp.pad_token_id(), max_seq_len=32, batch_pickle_dir=os.path.join(d, "train.batch"))
+    batches = [b for b in data.batches if 4 <= b["src_texts"].size(0) <= 8][:5]
+    assert len(batches) == 5 and all(b["src_texts"].size(1) <= 32 and b["dst_texts"].size(1) <= 32 for b in batches)
+    kw = dict(lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512, num_attention_heads=4)
+    torch.manual_seed(7)
+    ref = R.Seq2Seq(tp, **kw).eval()          # dropout off on both sides (parity run)
+    ours = Seq2Seq(tp, **kw)
+    ours.load_state_dict(ref.state_dict())
+    ours = ours.cuda().eval()
+    ours.set_compute_dtype(torch.float32)
+    opt_r = R.AdamInverseSqrtWithWarmup(ref.parameters(), lr=2e-3, betas=(0.9, 0.98), warmup_updates=3)
+    opt_o = AdamInverseSqrtWithWarmup(ours.parameters(), lr=2e-3, betas=(0.9, 0.98), warmup_updates=3)
+    crit = R.SmoothedNLLLoss(ignore_index=tp.pad_token_id())
+    lr_, lo_ = [], []
+    for rep in range(2):
+        for b in batches:
+            lr_.append(R.train_step(ref, opt_r, crit, b)[0])
+            loss, ntok = train_step(ours, opt_o, b)
+            lo_.append(float(loss))
+            assert ntok == int(b["dst_pad_mask"][:, 1:].sum())
+    for a, b_ in zip(lo_[:5], lr_[:5]):
+        assert a == pytest.approx(b_, rel=1e-4), (lo_, lr_)
+    assert lo_ == pytest.approx(lr_, rel=2e-3), "ten optimizer steps stay on the oracle's trajectory"
+    assert sum(lo_[5:]) < sum(lo_[:5]), "second pass over the same batches must have a lower loss"
+    k = "decoder.decoder.layer.1.crossattention.self.query.weight"
+    wr, wo = dict(ref.named_parameters())[k].detach(), dict(ours.named_parameters())[k].detach().cpu()
+    assert float((wr - wo).abs().max() / wr.abs().max()) < 2e-3
