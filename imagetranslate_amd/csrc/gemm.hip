@@ -1529,13 +1529,100 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
   }
 }
 
+// The same with the LayerNorm of the finished row behind it (dense + bias + dropout + residual + LayerNorm of BertSelfOutput /
+// BertOutput, src/bert_seq2seq.py:84-90,139-143, for few-row batches): one wave per row sums the slabs, applies the epilogue,
+// stores the LayerNorm INPUT rounded to T (what imt_layernorm_bwd reads) and normalises those rounded values with the
+// arithmetic of ln_fwd_kernel (rowops.hip) -- bit-identical to the epilogue launch + LayerNorm launch pair it replaces.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(const float* __restrict__ slabs, int64_t slab_elems, int splits, int M, int N,
+                                                                 EpiParams ep) {
+  const int lane = threadIdx.x & 63;
+  const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  const T* resid = reinterpret_cast<const T*>(ep.resid);
+  const T* gamma = reinterpret_cast<const T*>(ep.ln_gamma);
+  const T* beta = reinterpret_cast<const T*>(ep.ln_beta);
+  const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
+  f32x4 v[NCH], gv[NCH], bv[NCH];
+  // every load up front, unconditionally (columns past N read a clamped address and are masked where used)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = min(lane * 4 + i * 256, N - 4);
+    v[i] = Vec4<float>::load(slabs + (int64_t)row * N + c);
+    gv[i] = Vec4<T>::load(gamma + c);
+    bv[i] = Vec4<T>::load(beta + c);
+  }
+  for (int sidx = 1; sidx < splits; ++sidx)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] += Vec4<float>::load(slabs + sidx * slab_elems + (int64_t)row * N + min(lane * 4 + i * 256, N - 4));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256, cc = min(c, N - 4);
+    v[i] *= alpha;
+    if (bias) v[i] += Vec4<T>::load(bias + cc);
+    if (ep.drop_thresh) dropout_apply4(v[i], ep.seed, (uint64_t)row * (uint64_t)N + (uint64_t)cc, ep.drop_thresh, ep.inv_keep);
+    if (resid) v[i] += Vec4<T>::load(resid + (int64_t)row * ep.ldr + cc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = to_f32<T>(from_f32<T>(v[i][e]));
+    if (c < N) {
+      Vec4<T>::store(reinterpret_cast<T*>(ep.C) + (int64_t)row * ep.ldc + c, v[i]);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane * 4 + i * 256 < N) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mean; q += t * t; }
+    }
+  const float var = wave_sum(q) / (float)N;
+  const float rstd = 1.0f / sqrtf(var + ep.ln_eps);
+  if (lane == 0) {
+    if (ep.ln_mean) ep.ln_mean[row] = mean;
+    if (ep.ln_rstd) ep.ln_rstd[row] = rstd;
+  }
+  T* yr = reinterpret_cast<T*>(ep.ln_out) + (int64_t)row * ep.ld_ln;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < N) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gv[i][e] + bv[i][e];
+      Vec4<T>::store(yr + c, o);
+    }
+  }
+}
+
+template <typename T>
+int launch_splitk_epilogue_ln(const float* slabs, int64_t slab_elems, int S, int M, int N, const EpiParams& ep, hipStream_t st) {
+  const dim3 grid(imt_cdiv(M, 4));
+  switch (imt_cdiv(N, 256)) {
+    case 1: hipLaunchKernelGGL((splitk_epilogue_ln_kernel<T, 1>), grid, dim3(256), 0, st, slabs, slab_elems, S, M, N, ep); break;
+    case 2: hipLaunchKernelGGL((splitk_epilogue_ln_kernel<T, 2>), grid, dim3(256), 0, st, slabs, slab_elems, S, M, N, ep); break;
+    case 3: hipLaunchKernelGGL((splitk_epilogue_ln_kernel<T, 3>), grid, dim3(256), 0, st, slabs, slab_elems, S, M, N, ep); break;
+    default: hipLaunchKernelGGL((splitk_epilogue_ln_kernel<T, 4>), grid, dim3(256), 0, st, slabs, slab_elems, S, M, N, ep); break;
+  }
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
+}
+
 // how many K ranges for a product with `tiles` output tiles of 128 x 128 and `nt` K tiles; 1 = do not split
-int splitk_choice(int64_t tiles, int nt) {
+int splitk_choice(int64_t tiles, int nt, bool ln_fused) {
   static const int off = getenv("IMT_GEMM_NO_SMALL_SPLITK") ? 1 : 0;  // tuning / tests
-  if (off || tiles > 128 || nt < 16) return 1;
+  // with the LayerNorm in the epilogue launch the split costs no extra launch (it replaces the LayerNorm's), so a
+  // shorter K pays already when the product has only a handful of tiles (decoding: 320 rows)
+  static const int ln_min_nt = getenv("IMT_GEMM_SPLITK_LN_MIN_NT") ? atoi(getenv("IMT_GEMM_SPLITK_LN_MIN_NT")) : 8;
+  const bool short_ok = ln_fused && tiles <= 32 && nt >= ln_min_nt;
+  if (off || tiles > 128 || (nt < 16 && !short_ok)) return 1;
   int s = (int)(256 / tiles);
   if (s > 8) s = 8;
-  if (s > nt / 4) s = nt / 4;  // at least four K tiles per range: below that the ramp of a range costs more than it saves
+  const int per_min = (nt < 16) ? 2 : 4;  // K tiles per range: below that the ramp of a range costs more than it saves
+  if (s > nt / per_min) s = nt / per_min;
   if (s < 2) return 1;
   const int per = (nt + s - 1) / s;
   return (nt + per - 1) / per;  // every range non-empty
@@ -1678,7 +1765,8 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
   // few output tiles, long K, a workspace for partial sums: K ranges on the persistent kernel + one epilogue launch
   if (a->force_general == 0 && a->splitk_ws && splits == 1 && a->layout != IMT_TN && pipe_ok && a->N % 4 == 0 && !a->a_colsum) {
     const int64_t tiles = (int64_t)imt_cdiv(a->M, BM) * imt_cdiv(a->N, BN);
-    const int S = splitk_choice(tiles, a->K / bk);
+    const bool ln_fused = a->ln_out && a->aux_mode == IMT_AUX_NONE && a->N <= 1024 && !c_f32;
+    const int S = splitk_choice(tiles, a->K / bk, ln_fused);
     const int64_t rows_pad = (int64_t)imt_cdiv(a->M, BM) * BM;  // edge tiles store only rows < M, slabs are addressed [m][n] with ld N
     if (S > 1 && (int64_t)S * a->M * a->N * 4 <= a->splitk_ws_bytes && rows_pad > 0 && ((uintptr_t)a->splitk_ws & 15) == 0) {
       if (a->aux_mode != IMT_AUX_NONE) IMT_CHECK_ARG(a->aux != nullptr, "imt_gemm: aux_mode needs aux");
@@ -1703,6 +1791,15 @@ extern "C" int imt_gemm(const imt_gemm_args* a, void* stream) {
       ep.drop_thresh = dropout_thresh(a->dropout_p);
       ep.inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
       ep.seed = a->dropout_seed; ep.a_colsum = nullptr; ep.dbg = 0; ep.trace = nullptr; ep.slab_elems = 0;
+      if (ln_fused) {
+        // dense + bias + dropout + residual + LayerNorm: the epilogue launch normalises its rows itself
+        ep.ln_gamma = a->ln_gamma; ep.ln_beta = a->ln_beta; ep.ln_out = a->ln_out; ep.ld_ln = a->ld_ln;
+        ep.ln_mean = a->ln_mean; ep.ln_rstd = a->ln_rstd; ep.ln_eps = a->ln_eps;
+        ImtProfScope prof("gemm_splitk_epilogue_ln", 0.0, (double)a->M * a->N * (4.0 * S + 3.0 * es), st);
+        const float* slabs = reinterpret_cast<const float*>(a->splitk_ws);
+        return (a->dtype == IMT_F32) ? launch_splitk_epilogue_ln<float>(slabs, slab.slab_elems, S, a->M, a->N, ep, st)
+                                     : launch_splitk_epilogue_ln<bf16_t>(slabs, slab.slab_elems, S, a->M, a->N, ep, st);
+      }
       {
         const int64_t groups = (int64_t)a->M * (a->N / 4);
         ImtProfScope prof("gemm_splitk_epilogue", 0.0, (double)a->M * a->N * (4.0 * S + 2.0 * es), st);
