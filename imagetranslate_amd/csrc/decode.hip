@@ -187,15 +187,18 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_kernel(imt_beam_ar
   }
 }
 
+// 1024 threads per row (round 3): 320 rows on 256 CUs is two rounds of whatever ONE workgroup takes, and that is vector-instruction
+// time of the per-thread insertion lists -- 117 elements per thread at 256 threads, 29 at 1024 (55 -> ~25 us per step).
+constexpr int FAST_THREADS = 1024;
 // Same result in TWO passes over the row instead of 2 + beam (297 -> ~40 us per step at 320 rows x 30000): pass A is
 // an online (max, sum-exp) with 16-byte loads, pass B keeps each thread's own K best (score desc, index asc) in
 // registers -- a thread visits indices in increasing order, so strict '>' insertion keeps the lowest index first among
 // equal scores -- and K rounds of a block arg-best over the threads' list heads pick the row's K best in order.
 template <int K>
-__global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_fast_kernel(imt_beam_args a) {
-  __shared__ float red_f[BEAM_THREADS / 64];
-  __shared__ float red_g[BEAM_THREADS / 64];
-  __shared__ int red_i[BEAM_THREADS / 64];
+__global__ __launch_bounds__(FAST_THREADS) void beam_row_topk_fast_kernel(imt_beam_args a) {
+  __shared__ float red_f[FAST_THREADS / 64];
+  __shared__ float red_g[FAST_THREADS / 64];
+  __shared__ int red_i[FAST_THREADS / 64];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = r / a.rep;
   const float* x = a.logits + (int64_t)r * a.ld;
@@ -207,19 +210,19 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_fast_kernel(imt_be
   int* ci = a.cand_idx + (int64_t)r * a.beam;
   if (masked) {
     const float s = use_pen ? (cur + 0.0f) / pen : cur + 0.0f;
-    for (int t = tid; t < a.beam; t += BEAM_THREADS) { cs[t] = s; ci[t] = t; }
+    for (int t = tid; t < a.beam; t += FAST_THREADS) { cs[t] = s; ci[t] = t; }
     return;
   }
   const int V4 = a.V & ~3;
   // pass A: online max / sum-exp
   float m = -INFINITY, l = 0.f;
-  for (int v = tid * 4; v < V4; v += BEAM_THREADS * 4) {
+  for (int v = tid * 4; v < V4; v += FAST_THREADS * 4) {
     const f32x4 q = *reinterpret_cast<const f32x4*>(x + v);
     const float qm = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
     if (qm > m) { l *= __expf(m - qm); m = qm; }
     l += __expf(q[0] - m) + __expf(q[1] - m) + __expf(q[2] - m) + __expf(q[3] - m);
   }
-  for (int v = V4 + tid; v < a.V; v += BEAM_THREADS) {
+  for (int v = V4 + tid; v < a.V; v += FAST_THREADS) {
     const float q = x[v];
     if (q > m) { l *= __expf(m - q); m = q; }
     l += __expf(q - m);
@@ -227,11 +230,16 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_fast_kernel(imt_be
   float mx = wave_max(m);
   if (lane == 0) red_f[wv] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+  mx = red_f[0];
+#pragma unroll
+  for (int k = 1; k < FAST_THREADS / 64; ++k) mx = fmaxf(mx, red_f[k]);
   float sum = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - mx));
   if (lane == 0) red_g[wv] = sum;
   __syncthreads();
-  const float lse = mx + logf(red_g[0] + red_g[1] + red_g[2] + red_g[3]);
+  float tot = red_g[0];
+#pragma unroll
+  for (int k = 1; k < FAST_THREADS / 64; ++k) tot += red_g[k];
+  const float lse = mx + logf(tot);
   // pass B: per-thread top-K
   float ls[K]; int li[K];
 #pragma unroll
@@ -251,12 +259,12 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_fast_kernel(imt_be
       if (!placed) { ls[0] = sc; li[0] = v; }
     }
   };
-  for (int v = tid * 4; v < V4; v += BEAM_THREADS * 4) {
+  for (int v = tid * 4; v < V4; v += FAST_THREADS * 4) {
     const f32x4 q = *reinterpret_cast<const f32x4*>(x + v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) offer(q[e], v + e);
   }
-  for (int v = V4 + tid; v < a.V; v += BEAM_THREADS) offer(x[v], v);
+  for (int v = V4 + tid; v < a.V; v += FAST_THREADS) offer(x[v], v);
   // K rounds over the threads' list heads
   for (int t = 0; t < a.beam; ++t) {
     float bs = ls[0]; int bi = li[0];
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_row_topk_fast_kernel(imt_be
     __syncthreads();
     bs = red_f[0]; bi = red_i[0];
 #pragma unroll
-    for (int k = 1; k < BEAM_THREADS / 64; ++k)
+    for (int k = 1; k < FAST_THREADS / 64; ++k)
       if (better(red_f[k], red_i[k], bs, bi)) { bs = red_f[k]; bi = red_i[k]; }
     if (li[0] == bi) {  // this thread owned the winner: pop it
 #pragma unroll
@@ -385,8 +393,8 @@ extern "C" int imt_beam_step(const imt_beam_args* a, void* stream) {
   {
     ImtProfScope prof("beam_row_topk", 0, (double)rows * a->V * 4 * (2 + a->beam), st);
     const bool vec_ok = (a->ld % 4 == 0) && (((uintptr_t)a->logits & 15) == 0);
-    if (vec_ok && a->beam <= 4) hipLaunchKernelGGL(beam_row_topk_fast_kernel<4>, dim3(rows), dim3(BEAM_THREADS), 0, st, *a);
-    else if (vec_ok && a->beam <= 8) hipLaunchKernelGGL(beam_row_topk_fast_kernel<8>, dim3(rows), dim3(BEAM_THREADS), 0, st, *a);
+    if (vec_ok && a->beam <= 4) hipLaunchKernelGGL(beam_row_topk_fast_kernel<4>, dim3(rows), dim3(FAST_THREADS), 0, st, *a);
+    else if (vec_ok && a->beam <= 8) hipLaunchKernelGGL(beam_row_topk_fast_kernel<8>, dim3(rows), dim3(FAST_THREADS), 0, st, *a);
     else hipLaunchKernelGGL(beam_row_topk_kernel, dim3(rows), dim3(BEAM_THREADS), 0, st, *a);
     IMT_CHECK_LAUNCH();
   }
