@@ -166,7 +166,7 @@ def tune_dp_policy(sync, step, fence, device, backend, probe_steps=3):
     one while RCCL's kernels hold CUs (imt_set_gemm_share_cus); (2) whether the gradient buckets travel
     through torch.distributed's nccl backend or through the library's own RCCL communicator (imt_comm_*).  Each candidate
     runs `probe_steps` real train steps.  An axis pinned by its environment variable (IMT_GEMM_SHARE_CUS / IMT_COMM) is
-    not tuned.  Returns the choice and the probe times for the JSON line."""
+    not tuned; the communicator axis is probed only with IMT_BENCH_TUNE_COMM=1 (see below).  Returns the choice and the probe times for the JSON line."""
     import torch.distributed as dist
     from imagetranslate_amd import _lib as L
     from imagetranslate_amd.parallel import RcclComm
@@ -174,7 +174,10 @@ def tune_dp_policy(sync, step, fence, device, backend, probe_steps=3):
     share_axis = [None] if os.environ.get("IMT_GEMM_SHARE_CUS") is not None else [1, 0]
     comm_axis = ["torch-" + backend]
     rccl = None
-    if os.environ.get("IMT_COMM") is None and backend == "nccl" and sync.comm is None:
+    # The communicator axis is opt-in (IMT_BENCH_TUNE_COMM=1): imt_comm_* with more than one rank has never run on hardware
+    # (one-GPU boxes only), and a collective that misbehaves inside the benchmark would take the whole scaling run with it;
+    # the GEMM policy axis is a process-local switch and is always probed.
+    if os.environ.get("IMT_BENCH_TUNE_COMM") == "1" and os.environ.get("IMT_COMM") is None and backend == "nccl" and sync.comm is None:
         ok = torch.ones(1, device=device)
         try:
             rccl = RcclComm(dist.get_rank(), dist.get_world_size())
@@ -208,7 +211,7 @@ def tune_dp_policy(sync, step, fence, device, backend, probe_steps=3):
     sync.comm = rccl if best[0] == "imt-rccl" else None
     if best[1] is not None:
         lib.imt_set_gemm_share_cus(best[1])
-    return {"comm": best[0], "gemm_share_cus": "env" if best[1] is None else best[1],
+    return {"comm": best[0], "comm_axis_probed": len(comm_axis) > 1, "gemm_share_cus": "env" if best[1] is None else best[1],
             "probe_ms_per_step": {"%s,share_cus=%s" % k: round(v, 3) for k, v in probes.items()}}
 
 
