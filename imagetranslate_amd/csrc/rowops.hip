@@ -596,7 +596,8 @@ extern "C" int imt_embed_bwd(int dtype, const int64_t* ids, const int64_t* pos_i
   if (n_tokens <= 0) return IMT_OK;
   IMT_CHECK_ARG(ids && dsum && dword && dpos && dtype_tab, "embed_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  const int tokb = 16;
+  static const int tokb_env = getenv("IMT_EMBED_TOKB") ? atoi(getenv("IMT_EMBED_TOKB")) : 0;  // tuning only
+  const int tokb = tokb_env > 0 ? tokb_env : 16;
   const bool posmajor = (pos_ids == nullptr) && (n_tokens % seq_len == 0);  // must match the kernel's own test
   dim3 grid(posmajor ? seq_len * imt_cdiv(n_tokens / seq_len, tokb) : imt_cdiv(n_tokens, tokb));
   ImtProfScope prof("embed_bwd", 0.0, (double)n_tokens * d * ((dtype == IMT_BF16 ? 2 : 4) + 16.0), st);

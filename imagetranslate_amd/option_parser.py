@@ -4,8 +4,8 @@ lines (README.md:160-163, :212-216) parse here unchanged.  Kept as a table: (fla
 
 Flags the reference parses but never reads on this path (``--dropout``, ``--nll``, ``--dff``, ``--max_grad_norm``,
 ``--cache_size`` ...) are accepted and ignored; flags whose feature is outside the hot path
-(``--dict``, ``--lm`` for train_image_mt, ``--cont`` / ``--save-opt``, back-translation ``--langs``) are accepted by
-the parser and refused by the trainers (``reject_off_path``), never silently ignored.  Build additions, at the end of the table: ``--heads`` (the reference hard-codes 12,
+(``--dict``, ``--lm`` for train_image_mt, ``--cont`` / ``--save-opt``) are accepted by the parser and refused by the
+trainers (``reject_off_path``), never silently ignored; ``--langs`` / ``--fstep`` / ``--bt-beam`` drive the back-translation phase.  Build additions, at the end of the table: ``--heads`` (the reference hard-codes 12,
 src/lm_config.py:13), ``--fp32`` (compute in fp32; default is bf16 whether or not ``--fp16`` is given: apex fp16 maps to
 bf16 MFMA on MI355X), ``--seed``, ``--eval-steps`` / ``--log-steps`` / ``--save-steps`` (the reference hard-codes 5000 / 50 /
 10000, src/train_image_mt.py:302-325), ``--feat-dim`` (channels of the pre-extracted region features).

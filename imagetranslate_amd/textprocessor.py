@@ -43,6 +43,9 @@ class SyntheticTextProcessor:
     def lang_id(self, tok) -> int:
         return self.languages.get(tok, 0)
 
+    def id2token(self, id: int) -> str:
+        return self.special_tokens[int(id)] if 0 <= int(id) < len(self.special_tokens) else "tok%d" % int(id)
+
     def is_lang(self, id) -> bool:
         return 5 <= int(id) < 5 + len(self.languages)
 

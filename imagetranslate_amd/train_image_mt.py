@@ -1,13 +1,17 @@
 """Training entry point for the text path -- thin counterpart of src/train_image_mt.py (``ImageMTTrainer``
 ``:44-333`` and ``train`` ``:394-560``): supervised MT batches and/or MASS batches, label-smoothed loss, gradient
 clipping + inverse-sqrt Adam, dev-set loss, best-checkpoint saving, one process per GPU under torch.distributed.
-Everything the reference trainer does around the step that needs absent packages (apex, sacrebleu, torchvision
-image pipeline, back-translation scheduling) is left out; the model step itself is the HIP path."""
+Round 3 adds the back-translation phase (``--fstep`` / ``--langs`` / ``--bt-beam``, src/train_image_mt.py:108-198,509-533): after
+``--step`` ordinary steps the optimizer schedule is reset and every monolingual batch is translated by the model itself (KV-cached
+beam search, no gradient) and trained on as (translation -> original).  What the reference trainer does around the step that needs
+absent packages (apex, sacrebleu, the torchvision image pipeline) is left out; the model step itself is the HIP path."""
 import datetime
 import math
 import os
 import random
 import torch
+
+from torch.nn.utils.rnn import pad_sequence
 
 from . import dataset
 from .image_model import ImageMassSeq2Seq
@@ -33,6 +37,9 @@ class ImageMTTrainer:
         # MASS span / replacement draws: a generator of this rank's own, so that the ranks' batch ORDER (drawn from a
         # generator every rank seeds identically, below) never depends on how many MASS batches a rank has seen
         self._mass_rng = random.Random((seed + 1) * 7919 + rank)
+        self.generator = None  # BeamDecoder of the back-translation phase (built on first use)
+        self.bt_kw = dict(beam_width=kwargs.get("bt_beam_width", 1), max_len_a=kwargs.get("max_len_a", 1.3),
+                          max_len_b=kwargs.get("max_len_b", 5), len_penalty_ratio=kwargs.get("len_penalty_ratio", 0.8))
 
     def _finish_micro_step(self, loss, accum: int, scale: float):
         """clip after EVERY backward, step every `accum` (src/train_image_mt.py:291-295)."""
@@ -66,6 +73,48 @@ class ImageMTTrainer:
         self._finish_micro_step(loss, accum, scale)
         return loss.detach(), int(ntokens)
 
+    @staticmethod
+    def get_lang_dirs(bt_langs: str, text_processor):
+        """``--langs en,fa`` -> {token id of <en>: token id of <fa>, and back} (src/train_image_mt.py:535-548); None unless two
+        languages are given."""
+        langs = {text_processor.token_id("<" + l.strip() + ">") for l in (bt_langs or "").strip().split(",") if l.strip()}
+        if len(langs) < 2:
+            return None
+        assert len(langs) == 2, "back-translation is defined for one language pair (src/train_image_mt.py:541)"
+        a, b = sorted(langs)
+        return {a: b, b: a}
+
+    # one monolingual batch of the back-translation phase (src/train_image_mt.py:108-198, the is_mass_batch branch): translate the
+    # sentences into the other language with the current model (eval mode, no gradient: "we do not backpropagate the data
+    # generator following the MASS paper"), then train on (translation -> original)
+    def bt_step(self, batch, lang_directions, accum: int = 1):
+        from .seq_gen import BeamDecoder
+        model, tp = self.model, self.model.text_processor
+        pad = tp.pad_token_id()
+        src = batch["src_texts"]
+        src_mask = src != pad
+        first = [int(l) for l in src[:, 0]]
+        target_tags = torch.LongTensor([lang_directions[l] for l in first])               # first token of each translation
+        dst_langs = torch.LongTensor([tp.languages[tp.id2token(lang_directions[l])] for l in first])
+        if self.generator is None:
+            self.generator = BeamDecoder(model, **self.bt_kw)
+        was_training = model.training
+        model.eval()
+        with torch.no_grad():
+            outs = self.generator(src_inputs=src, src_sizes=batch["pad_idx"], first_tokens=target_tags, src_langs=batch["langs"],
+                                  tgt_langs=dst_langs, pad_idx=pad, src_mask=src_mask, unpad_output=False,
+                                  beam_width=self.bt_kw["beam_width"])
+        model.train(was_training)
+        translations = pad_sequence([o.cpu() for o in outs], batch_first=True, padding_value=pad)
+        if self.sync is not None:
+            self.sync.begin_step()
+        loss, ntokens = model.loss_fused(src_inputs=translations, tgt_inputs=src, src_langs=dst_langs, tgt_langs=batch["langs"],
+                                         pad_idx=pad)
+        loss.backward()
+        scale = self.sync.finish() if self.sync is not None else 1.0
+        self._finish_micro_step(loss, accum, scale)
+        return loss.detach(), int(ntokens)
+
     @torch.no_grad()
     def dev_loss(self, dev_data):
         self.model.eval()
@@ -91,7 +140,8 @@ class ImageMTTrainer:
         return order[self.rank::self.world_size]
 
     def train_epoch(self, mt_data=None, mass_data=None, dev_data=None, step: int = 0, max_step: int = 10 ** 9,
-                    save_path: str = None, log_every: int = 50, eval_every: int = 500, accum: int = 1):
+                    save_path: str = None, log_every: int = 50, eval_every: int = 500, accum: int = 1, fine_tune: bool = False,
+                    lang_directions=None):
         order = self.epoch_order(len(mt_data or []), len(mass_data or []))
         self.epoch += 1
         meter, t0 = LossMeter(), datetime.datetime.now()
@@ -99,7 +149,12 @@ class ImageMTTrainer:
             if step >= max_step:
                 break
             try:
-                loss, n = self.mt_step(mt_data[i], accum) if kind == "mt" else self.mass_step(mass_data[i], accum)
+                if kind == "mt":
+                    loss, n = self.mt_step(mt_data[i], accum)
+                elif fine_tune:  # back-translation phase: the monolingual batches are translated and trained on (:108-198)
+                    loss, n = self.bt_step(mass_data[i], lang_directions, accum)
+                else:
+                    loss, n = self.mass_step(mass_data[i], accum)
             except RuntimeError as err:  # the reference trainer skips a failing batch and goes on (:327-333)
                 if self.world_size > 1:
                     raise  # the other ranks are inside this step's collectives: skipping here would leave them hanging
@@ -171,9 +226,9 @@ def init_distributed():
 def reject_off_path(options, lm_supported: bool = False):
     """Flags whose feature is not built are refused, never silently ignored: a requested pretrained initialisation or a
     resumed optimizer that quietly trains from scratch is worse than an error."""
-    for flag, val in (("--dict", options.dict_path), ("--langs", options.bt_langs)):
+    for flag, val in (("--dict", options.dict_path),):
         if val:
-            raise NotImplementedError("%s: outside the hot path (lexical proposals / back-translation scheduling, DESIGN section 7)" % flag)
+            raise NotImplementedError("%s: outside the hot path (lexical proposals, DESIGN section 7)" % flag)
     for flag, val in (("--lm", None if lm_supported else options.lm_path), ("--cont", options.continue_train), ("--save-opt", options.save_opt)):
         if val:
             raise NotImplementedError("%s: not implemented by this trainer (masked-LM initialisation / pickled-optimizer resume, "
@@ -198,7 +253,8 @@ def train(options):
     optimizer = build_optimizer(model, options.learning_rate, options.warmup)
     # (GradSync broadcasts rank 0's parameters, like the DDP constructor at src/train_image_mt.py:73)
     trainer = ImageMTTrainer(model, mask_prob=options.mask_prob, clip=options.clip, optimizer=optimizer, rank=rank, world_size=world,
-                             seed=options.seed)
+                             seed=options.seed, bt_beam_width=options.bt_beam_width, max_len_a=options.max_len_a,
+                             max_len_b=options.max_len_b, len_penalty_ratio=options.len_penalty_ratio)
     pad = tp.pad_token_id()
     mk = lambda cls, path, **kw: cls(max_batch_capacity=options.total_capacity, max_batch=options.batch, pad_idx=pad,
                                      max_seq_len=options.max_seq_len, ngpu=1, **kw, **path)
@@ -221,6 +277,20 @@ def train(options):
         step = trainer.train_epoch(mt_data=mt_train, mass_data=mass_train, dev_data=mt_dev, step=step, max_step=options.step,
                                    save_path=options.model_path, log_every=options.log_steps, eval_every=options.eval_steps,
                                    accum=options.accum)
+    # back-translation phase (src/train_image_mt.py:509-533): optimizer schedule reset, then --fstep more steps in which the
+    # monolingual batches are back-translated.  The reference's flag default is 125000 steps; here the phase runs only when a
+    # language pair is given (--langs), which is what makes it well-defined.
+    lang_directions = ImageMTTrainer.get_lang_dirs(options.bt_langs, tp)
+    if lang_directions is not None and options.finetune_step > 0 and mass_train:
+        optimizer.reset()
+        total = step + options.finetune_step
+        for epoch in range(options.num_epochs):
+            if step >= total:
+                break
+            step = trainer.train_epoch(mt_data=None if options.ignore_mt_mass else mt_train, mass_data=mass_train, dev_data=mt_dev,
+                                       step=step, max_step=total, save_path=options.model_path, log_every=options.log_steps,
+                                       eval_every=options.eval_steps, accum=options.accum, fine_tune=True,
+                                       lang_directions=lang_directions)
     if mt_dev is not None:
         trainer.validate_and_save(mt_dev, options.model_path)
     elif rank == 0 and options.model_path:

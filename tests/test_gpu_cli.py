@@ -211,3 +211,73 @@ def test_config0_sample_corpus_against_oracle(cuda, tmp_path):
     k = "decoder.decoder.layer.1.crossattention.self.query.weight"
     wr, wo = dict(ref.named_parameters())[k].detach(), dict(ours.named_parameters())[k].detach().cpu()
     assert float((wr - wo).abs().max() / wr.abs().max()) < 2e-3
+
+
+def test_back_translation_step_against_oracle(cuda):
+    """The back-translation phase of the trainer (src/train_image_mt.py:108-198, monolingual batches): the model translates the
+    batch into the other language (greedy, no gradient), then takes a train step on (translation -> original).  Against the
+    oracle on the same weights: the generated token ids bit-exact, the loss within 1e-4, the target count equal; and the
+    command-line plumbing (--langs / --fstep / --bt-beam) resolves the language pair."""
+    from imagetranslate_amd.image_model import ImageMassSeq2Seq
+    from imagetranslate_amd.option_parser import get_img_options_parser
+    from imagetranslate_amd.textprocessor import SyntheticTextProcessor
+    from imagetranslate_amd.train_image_mt import ImageMTTrainer, reject_off_path
+    from imagetranslate_amd.utils import AdamInverseSqrtWithWarmup
+    from oracle import reference_model as R
+    from oracle.seq_gen import BeamDecoder as OracleBeam
+    from torch.nn.utils.rnn import pad_sequence
+    from tests.util import beam_state_dict
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "toy_seq2seq.pt"), weights_only=True)
+    kw = dict(lang_dec=False, enc_layer=2, dec_layer=2, embed_dim=128, intermediate_dim=512, num_attention_heads=4)
+    ref = R.Seq2Seq(R.SyntheticTextProcessor(1000), **kw)
+    ref.load_state_dict(beam_state_dict(fx["state_dict"]))
+    ref.eval()
+    tp = SyntheticTextProcessor(1000)
+    ours = ImageMassSeq2Seq(tp, **kw)
+    missing = ours.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing.unexpected_keys
+    ours = ours.cuda().eval()
+    ours.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(12)
+    B, S = 6, 14
+    src = torch.randint(7, 1000, (B, S), generator=g)
+    lens = torch.tensor([14, 9, 12, 7, 14, 10])
+    src[:, 0] = torch.tensor([5, 6, 5, 5, 6, 6])           # language tags <en> = 5, <fa> = 6 first
+    for b in range(B):
+        src[b, lens[b] - 1] = 4
+        src[b, lens[b]:] = 0
+    langs = (src[:, 0] - 5).clone()                          # language ids 0 / 1
+    batch = {"src_texts": src, "langs": langs, "pad_idx": torch.where(lens < S, lens, torch.full_like(lens, S - 1))}
+    dirs = ImageMTTrainer.get_lang_dirs("en,fa", tp)
+    assert dirs == {5: 6, 6: 5}
+    # expectation from the oracle, per one-language batch (as MassDataset builds them, src/dataset.py:212-269): greedy
+    # translations, then the smoothed NLL of (translation -> original); the reference's forward takes ONE target language per batch
+    from imagetranslate_amd.seq_gen import BeamDecoder
+    exp = []
+    for lang in (0, 1):
+        rows = (langs == lang).nonzero().view(-1)
+        tags = torch.LongTensor([dirs[int(t)] for t in src[rows, 0]])
+        dst_langs = tags - 5
+        gen_kw = dict(src_inputs=src[rows], src_sizes=batch["pad_idx"][rows], first_tokens=tags, src_langs=langs[rows], tgt_langs=dst_langs,
+                      pad_idx=0, src_mask=src[rows] != 0, unpad_output=False)
+        outs = OracleBeam(ref, beam_width=1, max_len_a=1.3, max_len_b=5)(**gen_kw)
+        got = BeamDecoder(ours, beam_width=1, max_len_a=1.3, max_len_b=5)(**gen_kw)
+        assert [o.tolist() for o in got] == [o.tolist() for o in outs], "back-translations must be the oracle's token ids"
+        trans = pad_sequence(outs, batch_first=True, padding_value=0)
+        lp = ref(trans, src[rows], trans != 0, src[rows] != 0, dst_langs, langs[rows], log_softmax=True)
+        tg = src[rows][:, 1:][(src[rows] != 0)[:, 1:]]
+        exp.append((float(R.SmoothedNLLLoss(ignore_index=0)(lp, tg).sum().detach()), int(tg.numel())))
+    opt = AdamInverseSqrtWithWarmup(ours.parameters(), lr=1e-4, betas=(0.9, 0.98), warmup_updates=10)
+    trainer = ImageMTTrainer(ours, optimizer=opt, clip=1.0, bt_beam_width=1)
+    w0 = dict(ours.named_parameters())["decoder.decoder.layer.0.output.dense.weight"].detach().clone()
+    for lang in (0, 1):   # one-language batches, as MassDataset builds them (src/dataset.py:212-269 groups by language)
+        rows = (langs == lang).nonzero().view(-1)
+        sub = {"src_texts": src[rows], "langs": langs[rows], "pad_idx": batch["pad_idx"][rows]}
+        loss, n = trainer.bt_step(sub, dirs)
+        assert n == exp[lang][1]
+        assert float(loss) == pytest.approx(exp[lang][0] / exp[lang][1], rel=2e-4 if lang == 0 else 5e-3)  # (second step: weights moved once)
+    w1 = dict(ours.named_parameters())["decoder.decoder.layer.0.output.dense.weight"].detach()
+    assert float((w1 - w0).abs().max()) > 0
+    o, _ = get_img_options_parser().parse_args(["--langs", "en,fa", "--fstep", "20", "--bt-beam", "1"])
+    reject_off_path(o)   # accepted since round 3
+    assert (o.bt_langs, o.finetune_step, o.bt_beam_width) == ("en,fa", 20, 1)

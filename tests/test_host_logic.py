@@ -71,10 +71,11 @@ def test_bench_self_launch_propagates_child_failure():
 
 
 def test_unimplemented_flags_are_refused_not_ignored():
-    """--lm (train_image_mt), --cont, --save-opt, --dict, --langs: parsed like the reference's flags, refused at use."""
+    """--lm (train_image_mt), --cont, --save-opt, --dict: parsed like the reference's flags, refused at use (--langs drives the
+    back-translation phase since round 3)."""
     from imagetranslate_amd.option_parser import get_img_options_parser
     from imagetranslate_amd.train_image_mt import reject_off_path
-    for argv in (["--lm", "x"], ["--cont"], ["--save-opt"], ["--dict", "d"], ["--langs", "en,fa"]):
+    for argv in (["--lm", "x"], ["--cont"], ["--save-opt"], ["--dict", "d"]):
         o, _ = get_img_options_parser().parse_args(argv)
         with pytest.raises(NotImplementedError):
             reject_off_path(o)
