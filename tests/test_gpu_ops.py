@@ -413,7 +413,7 @@ def _attn_ref(q, k, v, B, H, Tq, Tk, dh, mask):
     return (p @ vh).permute(0, 2, 1, 3).reshape(B * Tq, H * dh)
 
 
-@pytest.mark.parametrize("case", ["enc_keymask", "dec_causal_qmask", "cross_49", "mask3d", "long"])
+@pytest.mark.parametrize("case", ["enc_keymask", "dec_causal_qmask", "cross_49", "mask3d", "long", "mask3d_long", "causal_long"])
 @pytest.mark.parametrize("dh", [32, 64])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_fwd_bwd(cuda, dtype, dh, case):
@@ -421,7 +421,7 @@ def test_attention_fwd_bwd(cuda, dtype, dh, case):
     g = torch.Generator().manual_seed(7)
     B, H = 3, 4
     Tq, Tk = {"enc_keymask": (32, 32), "dec_causal_qmask": (127, 127), "cross_49": (31, 49), "mask3d": (20, 70),
-              "long": (130, 200)}[case]
+              "long": (130, 200), "mask3d_long": (150, 256), "causal_long": (256, 256)}[case]
     d = H * dh
     # q/k/v live in one wider buffer (fused QKV layout) for the self-attention cases
     q, qf = _mk((B * Tq, d), dtype, cuda, 1.0, g)
@@ -434,7 +434,7 @@ def test_attention_fwd_bwd(cuda, dtype, dh, case):
         lens = torch.randint(Tk // 2, Tk + 1, (B,), generator=g)
         key_mask = (torch.arange(Tk)[None] < lens[:, None])
         mask = key_mask[:, None, :].expand(B, Tq, Tk)
-    elif case == "dec_causal_qmask":
+    elif case in ("dec_causal_qmask", "causal_long"):
         lens = torch.randint(Tq // 2, Tq + 1, (B,), generator=g)
         query_mask = (torch.arange(Tq)[None] < lens[:, None])
         causal = True
@@ -843,7 +843,7 @@ def test_gemm_small_m_split_k_with_epilogues(cuda, dtype, layout):
     bk = 64 if dtype == torch.bfloat16 else 32
     tol = 3e-5 if dtype == torch.float32 else 1.5e-2
     ws = O.splitk_workspace(cuda)
-    for (M, N, nk, expect_split) in [(320, 512, 32, True), (992, 512, 32, True), (1000, 264, 24, True), (61, 128, 16, True),
+    for (M, N, nk, expect_split) in [(320, 512, 32, True), (992, 512, 32, True), (1000, 264, 24, True), (61, 128, 16, True), (1, 512, 32, True), (320, 200, 32, True),
                                      (320, 512, 8, False), (4224, 512, 32, False)]:
         K = nk * bk
         A, Af = _mk((M, K), dtype, cuda, 0.5, g)
