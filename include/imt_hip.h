@@ -219,6 +219,9 @@ int imt_embed_ln_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, cons
  *   query_mask[b, i] (uint8, nullable)  -- the tgt_mask.unsqueeze(-1) factor of future_mask (src/seq2seq.py:14-17)
  *   mask3d[b, i, j]  (uint8, nullable)  -- arbitrary 3-D tgt_attention_mask
  * lse[b,h,i] (fp32) = log-sum-exp of the masked scaled scores, saved for backward.
+ * Backward kernels (bf16): Tq, Tk <= 128 one fused single-workgroup kernel per (batch, head); 129..256 (MASS, BASELINE
+ * configs[4]: src/mass_seq2seq.py:32-60 runs the encoder over 256 tokens) its 256-key sibling; longer sequences and fp32 the
+ * dQ + dK/dV kernel pair.  All are free of cross-workgroup sums: bit-reproducible.
  */
 typedef struct imt_attn_args {
   int32_t dtype;
