@@ -174,6 +174,8 @@ SIGNATURES = {
     "imt_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P]),
     "imt_attention_fwd": (c_int, [POINTER(AttnArgs), _P]),
     "imt_attention_bwd": (c_int, [POINTER(AttnArgs), _P]),
+    "imt_attention_qkv_fwd_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "imt_attention_qkv_fwd": (c_int, [POINTER(AttnArgs), _P, c_int64, _P, _P, c_int, _P]),
     "imt_gather_rows": (c_int, [c_int, _P, c_int64, _P, _P, c_int64, c_int, c_int, _P]),
     "imt_scatter_rows": (c_int, [c_int, _P, c_int64, _P, _P, c_int64, c_int, c_int, _P]),
     "imt_log_softmax_fwd": (c_int, [c_int, _P, c_int64, _P, c_int64, _P, c_int, c_int, _P]),

@@ -951,6 +951,209 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused256_kernel(AttnP p) {
   }
 }
 
+// =========================================================================================== forward: q|k|v projection + attention
+// Self-attention of a short sequence (T <= 128, head_dim 64, bf16) with the q|k|v projection of BertSelfAttention
+// (src/bert_seq2seq.py:84-90,139-143 -> HF BertSelfAttention.query / key / value) INSIDE the attention launch: one workgroup
+// (8 waves) per (batch element, PAIR of heads) computes its 128 x 384 slice of x W^T + b -- q, k and v of its two heads, the
+// 128 rows being the batch element's tokens -- with the 256-tile kernel's loop (LDS-DMA of K tiles by all waves, two 64-KiB
+// stages, one barrier per K tile), stores it (the backward reads q|k|v) and parks it in LDS as the Q / K / V tiles of
+// attn_fwd_short_kernel, whose arithmetic then runs unchanged for the two heads.  Against the projection launch + attention
+// launch it saves one launch boundary, the 24-MB re-read of q|k|v and the second cold start.  Same k order per accumulator as
+// every GEMM kernel and the same attention code: results are bit-identical to the two-launch path.
+struct QkvP { const void* x; int64_t ldx; int64_t x_bytes; const void* w; const void* bias; int d_model; };
+
+// one wave's four 1-KiB pieces of a [128 rows][64 k] K-contiguous bf16 tile (the Dma struct of gemm.hip)
+struct QkvDma {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[4];
+  IMT_DEVICE void init(const bf16_t* base, int64_t ld, int64_t valid_bytes, int row0, int sub) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, (int)valid_bytes, 0x00020000);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = 64 * (4 * i + sub) + lane;
+      const int tr = q >> 3, pc = q & 7;
+      const int c = pc ^ swz<128>(tr);
+      voff[i] = (int)((((int64_t)(row0 + tr)) * ld + c * 8) * 2);
+    }
+  }
+  IMT_DEVICE void issue(char* tile, int sub, int t) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (4 * i + sub) * 1024), 16,
+                                               voff[i] + t * 128, 0, 0, 0);
+  }
+};
+
+template <bool UNUSED = false>
+__global__ __launch_bounds__(512, 2) void attn_qkv_fwd_kernel(AttnP p, QkvP g) {
+  typedef bf16_t T;
+  constexpr int DH = 64, RB = 128, NS = 2, NDT = 4;
+  typedef Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K loop: 2 stages x (x tile | Wq | Wk | Wv tiles of 16 KiB)
+  const int hp_n = p.H >> 1;
+  const int lid = imt_xcd_block(blockIdx.x, gridDim.x);
+  const int b = lid / hp_n, hp = lid % hp_n;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, gq = lane >> 4;
+  const int T_ = p.Tq, d = g.d_model;
+  const int nt = d >> 6;  // K tiles of 64 (host: d % 64 == 0)
+
+  // ---- phase A: [128 tokens] x [384 = q | k | v of two heads] = x_b W_sel^T
+  QkvDma d0, d1;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(g.x) + (int64_t)b * T_ * g.ldx;
+  const bf16_t* wq = reinterpret_cast<const bf16_t*>(g.w);
+  const int sub = wave & 3;
+  if (wave < 4) {  // waves 0-3 stream the x tile and the Wq tile, waves 4-7 the Wk and Wv tiles
+    d0.init(xb, g.ldx, g.x_bytes - (int64_t)b * T_ * g.ldx * 2, 0, sub);
+    d1.init(wq, d, (int64_t)3 * d * d * 2, hp * 128, sub);
+  } else {
+    d0.init(wq, d, (int64_t)3 * d * d * 2, d + hp * 128, sub);
+    d1.init(wq, d, (int64_t)3 * d * d * 2, 2 * d + hp * 128, sub);
+  }
+  const int t0 = wave < 4 ? 0 : 2;  // first of this wave's two sub-tiles within a stage
+  auto issue = [&](int slot, int t) {
+    d0.issue(smem + slot * 65536 + t0 * 16384, sub, t);
+    d1.issue(smem + slot * 65536 + (t0 + 1) * 16384, sub, t);
+  };
+  const int wm = (wave >> 2) * 64, c0 = (wave & 3) * 96;  // this wave's 64 rows x 96 columns
+  f32x4 acc[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (t + 1 < nt) issue((t + 1) & 1, t + 1);
+    const char* st = smem + (t & 1) * 65536;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      frag_t fa[4], fb[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int c = c0 + 16 * j;
+        fb[j] = lds_frag_kcontig<T, RB>(st + (1 + (c >> 7)) * 16384, c & 127, 4 * s);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = lds_frag_kcontig<T, RB>(st, wm + 16 * i, 4 * s);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) mma16(acc[i][j], fb[j], fa[i]);  // C^T tile: rows <- n, cols <- m
+    }
+  }
+  __syncthreads();  // every wave is done with the last K tile: the stages become the Q / K / V tiles
+
+  // ---- phase B: + bias, store q|k|v (the backward reads them), park them as [which][head][128 rows][64] bf16 tiles
+  char* tiles = smem;                       // tile (which, hh) at ((which * 2 + hh) * 16384)
+  uint8_t* kmask_s = reinterpret_cast<uint8_t*>(smem + 6 * 16384);
+  {
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(g.bias);
+    bf16_t* outs[3] = {reinterpret_cast<bf16_t*>(const_cast<void*>(p.Q)), reinterpret_cast<bf16_t*>(const_cast<void*>(p.K)),
+                       reinterpret_cast<bf16_t*>(const_cast<void*>(p.V))};
+    const int64_t lds_[3] = {p.ldq, p.ldk, p.ldv};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int c = c0 + 16 * j + 4 * gq;        // column of the 384: which = c >> 7, head = (c >> 6) & 1, dim = c & 63
+      const int which = c >> 7, hh = (c >> 6) & 1, dim = c & 63;
+      const int gcol = which * d + hp * 128 + (c & 127);
+      const f32x4 bv = bias ? Vec4<T>::load(bias + gcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16_t* ob = outs[which] + (int64_t)b * T_ * lds_[which] + hp * 128 + (c & 127);
+      char* tl = tiles + (which * 2 + hh) * 16384;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = wm + 16 * i + r;
+        const f32x4 v = acc[i][j] * 1.0f + bv;
+        bf16x4 w4 = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        if (m >= T_) w4 = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};  // rows of the next batch element / past the end
+        else *reinterpret_cast<bf16x4*>(ob + (int64_t)m * lds_[which]) = w4;
+        *reinterpret_cast<bf16x4*>(tl + tile_off<RB>(m, dim >> 3) + ((dim & 7) << 1)) = w4;
+      }
+    }
+    if (threadIdx.x < 128) {
+      const int j = threadIdx.x;
+      kmask_s[j] = (j < p.Tk) ? (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + j] : (uint8_t)1) : (uint8_t)0;
+    }
+  }
+  const int q0 = wave * 16, i = q0 + r;
+  const uint8_t* qmp = p.query_mask ? p.query_mask + (int64_t)b * p.Tq + min(i, p.Tq - 1) : reinterpret_cast<const uint8_t*>(g.w);
+  const uint8_t qmv = *qmp;
+  const bool query_ok = (p.query_mask && i < p.Tq) ? (qmv != 0) : true;
+  __syncthreads();
+  if (q0 >= p.Tq) return;  // whole wave past the last query (no barrier follows)
+
+  // ---- phase C: attn_fwd_short_kernel's arithmetic for the two heads
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    const int h = 2 * hp + hh;
+    const char* Qs = tiles + (0 * 2 + hh) * 16384;
+    const char* Ks = tiles + (1 * 2 + hh) * 16384;
+    const char* Vs = tiles + (2 * 2 + hh) * 16384;
+    frag_t qf[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) qf[ks] = lds_frag_kcontig<T, RB>(Qs, q0, 4 * ks);
+    f32x4 s[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int nt8 = 0; nt8 < 8; ++nt8) {
+      s[nt8] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) mma16(s[nt8], lds_frag_kcontig<T, RB>(Ks, 16 * nt8, 4 * ks), qf[ks]);
+      const uint32_t km4 = *reinterpret_cast<const uint32_t*>(kmask_s + 16 * nt8 + 4 * gq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = 16 * nt8 + 4 * gq + e;
+        float v = s[nt8][e] * p.scale + (mask_ok<false>(p, b, i, j, ((km4 >> (8 * e)) & 0xffu) != 0, query_ok) ? 0.f : -10000.0f);
+        if (j >= p.Tk) v = -INFINITY;
+        s[nt8][e] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    float psum = 0.f;
+#pragma unroll
+    for (int nt8 = 0; nt8 < 8; ++nt8)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = __expf(s[nt8][e] - tmax);
+        psum += pv;
+        s[nt8][e] = pv;
+      }
+    if (p.drop_thresh) {
+      const uint32_t key = dropout_key(p.seed);
+      const uint32_t prow = (uint32_t)attn_pair_row(p, b, h, i) + (uint32_t)(2 * gq);
+#pragma unroll
+      for (int nt8 = 0; nt8 < 8; ++nt8)
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const uint32_t w = attn_drop_word(key, prow + 8 * nt8 + e2);
+          s[nt8][2 * e2] = (w & 0xffffu) >= p.drop_thresh ? s[nt8][2 * e2] * p.inv_keep : 0.f;
+          s[nt8][2 * e2 + 1] = (w >> 16) >= p.drop_thresh ? s[nt8][2 * e2 + 1] * p.inv_keep : 0.f;
+        }
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    f32x4 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const frag_t pf = acc_pair_to_frag(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) mma16(o[dt], lds_frag_kperm_bf16<RB>(Vs, 32 * u, 16 * dt), pf);
+    }
+    const float inv_l = 1.0f / psum;
+    if (i < p.Tq) {
+      T* Ob = reinterpret_cast<T*>(p.O) + ((int64_t)b * p.Tq + i) * p.ldo + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) Vec4<T>::store(Ob + 16 * dt + 4 * gq, o[dt] * inv_l);
+      if (gq == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Tq + i] = tmax + __logf(psum);
+    }
+  }
+}
+
 int check_args(const imt_attn_args* a, bool bwd) {
   IMT_CHECK_ARG(a != nullptr, "attention: null args");
   IMT_CHECK_ARG(a->dtype == IMT_F32 || a->dtype == IMT_BF16, "attention: bad dtype");
@@ -1086,4 +1289,38 @@ extern "C" int imt_attention_bwd(const imt_attn_args* a, void* stream) {
     return a->head_dim == 32 ? bwd_fused256_launch<32, false>(p, st) : bwd_fused256_launch<64, false>(p, st);
   }
   return a->head_dim == 32 ? bwd_launch<bf16_t, 32>(p, st) : bwd_launch<bf16_t, 64>(p, st);
+}
+
+// q|k|v projection + self-attention forward in one launch (attn_qkv_fwd_kernel).  a: the attention arguments with Q / K / V
+// pointing at the OUTPUT views of the projection (element (b, t, h, e) as for imt_attention_fwd); x [B*T, d_model] (ldx), w
+// [3 d_model, d_model] row-major (q rows first, then k, then v: the runtime's fused projection weight), bias [3 d_model] or NULL.
+extern "C" int imt_attention_qkv_fwd_supported(int dtype, int head_dim, int H, int Tq, int Tk, int d_model, int has_mask3d) {
+  return dtype == IMT_BF16 && head_dim == 64 && H % 2 == 0 && H * head_dim == d_model && Tq == Tk && Tq > 64 && Tq <= 128 &&
+         d_model % 64 == 0 && d_model >= 128 && !has_mask3d;
+}
+extern "C" int imt_attention_qkv_fwd(const imt_attn_args* a, const void* x, int64_t ldx, const void* w, const void* bias, int d_model,
+                                     void* stream) {
+  int rc = check_args(a, false);
+  if (rc) return rc;
+  IMT_CHECK_ARG(x && w && ldx % 8 == 0 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "attention_qkv_fwd: x / w missing or misaligned");
+  IMT_CHECK_ARG(imt_attention_qkv_fwd_supported(a->dtype, a->head_dim, a->H, a->Tq, a->Tk, d_model, a->mask3d != nullptr),
+                "attention_qkv_fwd: unsupported shape (bf16, head_dim 64, even heads, 64 < T <= 128, self-attention, no 3-D mask)");
+  IMT_CHECK_ARG((double)a->B * a->H * a->Tq * a->Tk < 4294967296.0 && (int64_t)a->B * a->Tq * ldx * 2 < (1ll << 31) &&
+                (int64_t)3 * d_model * d_model * 2 < (1ll << 31), "attention_qkv_fwd: operand too large for 32-bit offsets");
+  const AttnP p = make_params(a);
+  QkvP g;
+  g.x = x; g.ldx = ldx; g.x_bytes = ((int64_t)(a->B * a->Tq - 1) * ldx + d_model) * 2; g.w = w; g.bias = bias; g.d_model = d_model;
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 2 * 65536;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_qkv_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const double work = (double)p.B * p.H * p.Tq * p.Tk * a->head_dim;
+  ImtProfScope prof("attn_qkv_fwd_bf16", 4.0 * work + 2.0 * p.B * p.Tq * 3.0 * d_model * d_model,
+                    ((double)p.B * p.Tq * d_model * 2.0) * 5.0 + 6.0 * d_model * d_model, st);
+  hipLaunchKernelGGL((attn_qkv_fwd_kernel<false>), dim3(p.B * (p.H / 2)), dim3(512), lds, st, p, g);
+  IMT_CHECK_LAUNCH();
+  return IMT_OK;
 }

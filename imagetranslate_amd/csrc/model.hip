@@ -283,9 +283,17 @@ int attn_block_fwd(const Ctx& c, const imt_attn_block& p, AttnWs& w, const void*
   const float hp = training ? c.m->hidden_dropout : 0.f, ap = training ? c.m->attn_dropout : 0.f;
   imt_attn_args a;
   if (!kv_src) {
-    RC(linear_fwd(c, x, d, N, d, p.qkv_w, p.qkv_b, 3 * d, w.qkv, 3 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
     attn_args(c, a, B, T, T, w.qkv, 3 * d, offp(w.qkv, d, c.es), 3 * d, offp(w.qkv, 2 * d, c.es), 3 * d, w.ctx, w.lse, ms, ap,
               site_seed(seed, layer, site0));
+    // short self-attention in bf16: the q|k|v projection runs inside the attention launch (bit-identical to the pair)
+    static const bool qkv_fusion = getenv("IMT_ATTN_QKV_FUSION") && atoi(getenv("IMT_ATTN_QKV_FUSION")) != 0;  // measured neutral on C1: opt-in
+    if (qkv_fusion && p.qkv_b >= 0 && imt_attention_qkv_fwd_supported(c.dtype, a.head_dim, a.H, T, T, d, ms.m3d != nullptr) &&
+        (int64_t)B * T * d * c.es < (1ll << 31)) {
+      RC(imt_attention_qkv_fwd(&a, x, d, c.P(p.qkv_w), c.P(p.qkv_b), d, c.st));
+      RC(dense_resid_ln(c, w.ctx, d, N, d, p.o_w, p.o_b, d, x, p.ln_g, p.ln_b, w.pre_ln, w.out, w.mean, w.rstd, hp, site_seed(seed, layer, site0 + 1)));
+      return IMT_OK;
+    }
+    RC(linear_fwd(c, x, d, N, d, p.qkv_w, p.qkv_b, 3 * d, w.qkv, 3 * d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));
   } else {
     const int Nk = B * Tk;
     RC(linear_fwd(c, x, d, N, d, p.qkv_w, p.qkv_b, d, w.qkv, d, nullptr, 0, nullptr, IMT_AUX_NONE, 0.f, 0));

@@ -267,6 +267,23 @@ def attention_fwd(q, k, v, B, H, Tq, Tk, head_dim, key_mask=None, query_mask=Non
     return o, lse
 
 
+def attention_qkv_fwd(x, w_qkv, b_qkv, B, H, T, head_dim, key_mask=None, query_mask=None, causal=False, scale=None,
+                      dropout_p=0.0, dropout_seed=0):
+    """(qkv [B*T, 3d], o [B*T, d], lse) = q|k|v projection + self-attention forward in ONE launch (imt_attention_qkv_fwd);
+    x [B*T, d], w_qkv [3d, d] (query rows first), b_qkv [3d] or None."""
+    _req_cuda(x, w_qkv, b_qkv, key_mask, query_mask)
+    d = H * head_dim
+    qkv = torch.empty((B * T, 3 * d), device=x.device, dtype=x.dtype)
+    a = _attn_args(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, head_dim, key_mask, query_mask, None, causal, scale,
+                   dropout_p, dropout_seed)
+    o = torch.empty((B * T, d), device=x.device, dtype=x.dtype)
+    lse = torch.empty((B, H, T), device=x.device, dtype=torch.float32)
+    a.O, a.ldo, a.lse = o.data_ptr(), _rowmajor(o), lse.data_ptr()
+    L.check(L.load().imt_attention_qkv_fwd(ctypes.byref(a), _p(x), _rowmajor(x), _p(w_qkv), _p(b_qkv), d, _stream()),
+            "imt_attention_qkv_fwd")
+    return qkv, o, lse
+
+
 def attention_bwd(do, q, k, v, o, lse, B, H, Tq, Tk, head_dim, key_mask=None, query_mask=None, mask3d=None,
                   causal=False, scale=None, dropout_p=0.0, dropout_seed=0, dq=None, dk=None, dv=None):
     _req_cuda(do, q, k, v, o, lse)

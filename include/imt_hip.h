@@ -247,6 +247,15 @@ typedef struct imt_attn_args {
 } imt_attn_args;
 int imt_attention_fwd(const imt_attn_args* a, void* stream);
 int imt_attention_bwd(const imt_attn_args* a, void* stream);
+/* BertSelfAttention's query / key / value projections INSIDE the attention forward (round 3): one launch computes
+ * q|k|v = x W^T + b for a short self-attention (bf16, head_dim 64, even number of heads, 64 < T <= 128, no 3-D mask; one
+ * workgroup per batch element and pair of heads), stores them through a->Q / a->K / a->V -- which here are OUTPUT views of
+ * the projection buffer, element (b, t, h, e) as above -- and continues with the attention of imt_attention_fwd on them:
+ * a->O, a->lse as there.  x [B*T, d_model] (ldx), w [3 d_model, d_model] row-major with the query rows first, then key, then
+ * value (the runtime's fused projection weight), bias [3 d_model] or NULL.  Bit-identical to imt_gemm + imt_attention_fwd. */
+int imt_attention_qkv_fwd_supported(int dtype, int head_dim, int H, int Tq, int Tk, int d_model, int has_mask3d);
+int imt_attention_qkv_fwd(const imt_attn_args* a, const void* x, int64_t ldx, const void* w, const void* bias, int d_model,
+                          void* stream);
 
 /* ------------------------------------------------------------------ row select (src/seq2seq.py:175-177)
  * gather: out[r,:] = x[idx[r],:] ; scatter (its backward): dx[idx[r],:] = dout[r,:] (dx pre-zeroed by caller

@@ -905,3 +905,34 @@ def test_gemm_split_k_long_ragged_k(cuda):
     out, kinds = _kinds(lambda: O.gemm(A, B, O.IMT_NN, alpha_dev=gdev, splitk_ws=O.splitk_workspace(cuda)))
     assert "gemm_splitk_epilogue" in kinds, kinds
     assert_close(out, 0.5 * (Af @ Bf), 1.5e-2, "ragged K + split-K")
+
+
+@pytest.mark.parametrize("T,H,causal,drop", [(128, 8, False, 0.1), (127, 8, True, 0.1), (100, 4, False, 0.0), (65, 2, True, 0.0), (128, 8, True, 0.0)])
+def test_attention_with_fused_qkv_projection_is_bit_identical(cuda, T, H, causal, drop):
+    """q|k|v projection + short self-attention in one launch (imt_attention_qkv_fwd) against imt_gemm + imt_attention_fwd on the
+    same inputs: q|k|v, the context and the log-sum-exp must be BIT-identical (same k order per accumulator, same attention
+    code), with key padding, a query mask, causal masking and dropout; rows of the next batch element that the 128-row tile
+    touches (T < 128) must not leak into the result."""
+    from imagetranslate_amd import hip_ops as O
+    g = torch.Generator().manual_seed(41)
+    B, dh = 5, 64
+    d = H * dh
+    x = (torch.randn(B * T, d, generator=g) * 0.7).bfloat16().cuda()
+    w = (torch.randn(3 * d, d, generator=g) * 0.06).bfloat16().cuda()
+    bias = (torch.randn(3 * d, generator=g) * 0.1).bfloat16().cuda()
+    klen = torch.randint(T // 2, T + 1, (B,), generator=g)
+    kmask = (torch.arange(T)[None] < klen[:, None]).to(torch.uint8).cuda()
+    qmask = (torch.rand(B, T, generator=g) > 0.1).to(torch.uint8).cuda() if causal else None
+    kw = dict(key_mask=kmask, query_mask=qmask, causal=causal, dropout_p=drop, dropout_seed=777)
+    qkv_ref = O.gemm(x, w, O.IMT_NT, bias=bias)
+    o_ref, lse_ref = O.attention_fwd(qkv_ref[:, :d], qkv_ref[:, d:2 * d], qkv_ref[:, 2 * d:], B, H, T, T, dh, **kw)
+    (qkv, o, lse), kinds = _kinds(lambda: O.attention_qkv_fwd(x, w, bias, B, H, T, dh, **kw))
+    assert "attn_qkv_fwd_bf16" in kinds, kinds
+    assert torch.equal(qkv, qkv_ref), "q|k|v differ (max %g)" % float((qkv.float() - qkv_ref.float()).abs().max())
+    assert torch.equal(o, o_ref), "context differs (max %g)" % float((o.float() - o_ref.float()).abs().max())
+    assert torch.equal(lse, lse_ref)
+    # without a bias
+    qkv_nb, o_nb, _ = O.attention_qkv_fwd(x, w, None, B, H, T, dh, **kw)
+    qr = O.gemm(x, w, O.IMT_NT)
+    assert torch.equal(qkv_nb, qr)
+    assert torch.equal(o_nb, O.attention_fwd(qr[:, :d], qr[:, d:2 * d], qr[:, 2 * d:], B, H, T, T, dh, **kw)[0])
