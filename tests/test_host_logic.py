@@ -83,3 +83,20 @@ def test_unimplemented_flags_are_refused_not_ignored():
     reject_off_path(o, lm_supported=True)  # train_captioning adopts a pretrained MT model through --lm
     o, _ = get_img_options_parser().parse_args([])
     reject_off_path(o)
+
+
+def test_active_head_hint_is_refused_inside_an_accumulation_window():
+    """An idle head is left out of the gradient exchange but scaled by 1/world with the whole buffer: inside a --acc window that
+    would shrink a head that was active in an earlier micro-step.  train_step refuses the combination before touching anything."""
+    from imagetranslate_amd.parallel import train_step
+
+    class FakeSync:
+        world_size = 2
+        def begin_step(self, head=None):
+            raise AssertionError("the guard must fire first")
+    with pytest.raises(ValueError):
+        train_step(None, None, {}, sync=FakeSync(), update=False, active_head=0)
+    s = FakeSync()
+    s._window_open = True   # an earlier micro-step of this window did not update
+    with pytest.raises(ValueError):
+        train_step(None, None, {}, sync=s, update=True, active_head=1)
