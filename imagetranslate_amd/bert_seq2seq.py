@@ -239,9 +239,29 @@ class _Pretrained(nn.Module):
         if dev.type != "cuda":
             raise L.ImtError("imagetranslate_amd: model parameters are on %s; the HIP path needs the GPU "
                              "(no CPU fallback) -- call model.cuda() first" % dev)
-        ids = ids.to(dev).contiguous()
-        type_ids = None if type_ids is None else type_ids.to(dev).contiguous()
-        pos_ids = None if pos_ids is None else pos_ids.to(dev).contiguous()
+        if ids.dim() != 2:
+            raise ValueError("input_ids must be [batch, length], got %s" % (tuple(ids.shape),))
+        # the runtime takes raw pointers: every operand's shape is checked HERE against what the kernels will index
+        # (a [batch] token_type_ids, as Seq2Seq.forward holds before it expands it, would otherwise be read out of bounds)
+        B_, T_ = ids.shape
+        def shaped(t, name, *shape):
+            if t is not None and tuple(t.shape) != shape:
+                raise ValueError("%s must be %s, got %s" % (name, list(shape), list(t.shape)))
+        if type_ids is not None and tuple(type_ids.shape) in ((B_,), (B_, 1)):
+            type_ids = type_ids.reshape(B_, 1).expand(B_, T_)   # one language id per sentence (src/seq2seq.py:96)
+        if pos_ids is not None and tuple(pos_ids.shape) in ((T_,), (1, T_)):
+            pos_ids = pos_ids.reshape(1, T_).expand(B_, T_)      # HF broadcasts a [1, length] position_ids
+        shaped(type_ids, "token_type_ids", B_, T_)
+        shaped(pos_ids, "position_ids", B_, T_)
+        shaped(key_mask, "attention mask", B_, T_)
+        shaped(query_mask, "tgt_query_mask", B_, T_)
+        shaped(mask3d, "3-D attention mask", B_, T_, T_)
+        if enc_states is not None:
+            if enc_states.dim() != 3 or enc_states.shape[0] != B_ or enc_states.shape[2] != self.config.hidden_size:
+                raise ValueError("encoder_states must be [%d, source_len, %d], got %s" % (B_, self.config.hidden_size, list(enc_states.shape)))
+            shaped(enc_mask, "encoder_attention_mask", B_, enc_states.shape[1])
+        i64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.long).contiguous()   # the kernels index int64_t
+        ids, type_ids, pos_ids = i64(ids), i64(type_ids), i64(pos_ids)
         def u8(m):  # masks as bytes: a bool tensor already is one byte per element (reinterpret, no conversion kernel)
             if m is None:
                 return None

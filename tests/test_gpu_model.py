@@ -449,6 +449,34 @@ def test_decoder_mask_variants_and_standalone_calls(cuda):
         assert out.shape == (8, 1000)
 
 
+def test_stack_operand_shapes_are_checked_on_the_host(cuda):
+    """The runtime takes raw pointers, so a mis-shaped operand must be refused before anything is launched (a [batch]
+    token_type_ids read as [batch, length] faulted the GPU once); per-sentence language ids, [1, length] positions and
+    int32 ids are accepted the way torch / HF broadcasting would take them and give the same states."""
+    _, ours = _pair()
+    b = _toy_batch()
+    S = b["src_texts"].shape[1]
+    ids, mask, langs = b["src_texts"].cuda(), b["src_pad_mask"].cuda(), b["src_langs"].cuda()
+    with torch.no_grad():
+        want = ours.encode(ids, mask, langs.unsqueeze(-1).expand(-1, S))[0]
+        assert torch.equal(ours.encode(ids, mask, langs)[0], want)                          # [batch] language ids
+        assert torch.equal(ours.encode(ids.int(), mask, langs.int().unsqueeze(-1))[0], want)  # int32, [batch, 1]
+        pos = torch.arange(S, device="cuda").unsqueeze(0)
+        assert torch.equal(ours.encoder(ids, attention_mask=mask, token_type_ids=langs, position_ids=pos), want)
+        for bad in (dict(attention_mask=mask[:, :-1]), dict(token_type_ids=langs[:-1]), dict(position_ids=pos[:, :-1]),
+                    dict(attention_mask=mask[:-1])):
+            kw = dict(attention_mask=mask, token_type_ids=langs)
+            kw.update(bad)
+            with pytest.raises(ValueError):
+                ours.encoder(ids, **kw)
+        with pytest.raises(ValueError):
+            ours.decoder(encoder_states=want[:-1], input_ids=ids, encoder_attention_mask=mask, token_type_ids=langs)
+        with pytest.raises(ValueError):
+            ours.decoder(encoder_states=want, input_ids=ids, encoder_attention_mask=mask[:, :-1], token_type_ids=langs)
+        with pytest.raises(ValueError):
+            ours.decoder(encoder_states=want[:, :, :-8], input_ids=ids, encoder_attention_mask=mask, token_type_ids=langs)
+
+
 def test_save_load_roundtrip(cuda, tmp_path):
     import imagetranslate_amd.seq2seq as S
     ref, ours = _pair()
