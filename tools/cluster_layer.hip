@@ -16,6 +16,9 @@
 #include "../imagetranslate_amd/csrc/mma.hpp"
 
 typedef bf16_t T;
+#ifndef XCD_LOCAL
+#define XCD_LOCAL 0   // 1: hand-offs through the XCD's own L2 (plain stores, plain operand loads): valid only while a cluster sits on one XCD
+#endif
 typedef Frag<T>::type frag_t;
 typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int RB = 128, TT = 128, D = 512, FF = 2048, MAXL = 8;
@@ -26,6 +29,11 @@ struct LayerW { const T *wqkv, *bqkv, *wo, *bo, *g1, *b1, *w1, *bf1, *w2, *bf2, 
 struct LayerBuf { T *qkv, *ctx, *y1, *pre, *h, *y2; float *st1, *st2; };   // st*: [4 members][rows][2] floats
 struct ClP { unsigned long long* trace; const T* x0; LayerW w[MAXL]; LayerBuf buf[MAXL]; unsigned* flags; unsigned* status; int layers; int rows; unsigned epoch0; float scale; };
 
+#if XCD_LOCAL
+#define STORE_HANDOFF(p, v) Vec4<T>::store(p, v)
+#else
+#define STORE_HANDOFF(p, v) Vec4<T>::store_wt(p, v)
+#endif
 IMT_DEVICE unsigned ld_rlx(const unsigned* p) { return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 IMT_DEVICE void st_rlx(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 IMT_DEVICE f32x2 ld_sc1_f2(const float* p) {
@@ -71,7 +79,7 @@ template <int NJ, int S> struct Slice {   // S ring stages of (16 + 8 NJ) KiB
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(stage + (wave + 8 * i) * 1024), 16,
-                                               va[i] + t * 128, 0, 0, 16 /* sc1 */);
+                                               va[i] + t * 128, 0, 0, XCD_LOCAL ? 0 : 16 /* sc1 */);
   }
   // W tile 0 was requested into stage 0 by the caller (before it waited for the peers); acc += A W^T over K
   IMT_DEVICE void run(char* smem, int K, f32x4 (&acc)[4][NJ]) const {
@@ -195,7 +203,7 @@ IMT_DEVICE bool resid_ln(f32x4 (&v)[4][2], const T* bias, const T* resid /* [row
     for (int j = 0; j < 2; ++j) {
       const int c = col0 + c0 + 16 * j + 4 * gq;
       const f32x4 y = (v[i][j] - mean) * rstd * Vec4<T>::load(gamma + c) + Vec4<T>::load(beta + c);
-      Vec4<T>::store_wt(out + (row0 + m) * D + c, y);
+      STORE_HANDOFF(out + (row0 + m) * D + c, y);
     }
   }
   return true;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void cluster_layers(ClP p) {
         const float inv_l = 1.0f / psum;
         T* Ob = o.ctx + (row0 + i) * D + h * 64;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) Vec4<T>::store_wt(Ob + 16 * dt + 4 * gq, ov[dt] * inv_l);
+        for (int dt = 0; dt < 4; ++dt) STORE_HANDOFF(Ob + 16 * dt + 4 * gq, ov[dt] * inv_l);
       }
       ++epoch;
       cl.publish(epoch);   // hand-off 1: context slices (the barrier inside also frees the tiles)
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void cluster_layers(ClP p) {
             const int m = wm + 16 * i + r;
             const f32x4 z = acc[i][j] + bv;
             Vec4<T>::store(o.pre + (row0 + m) * FF + c, z);
-            Vec4<T>::store_wt(o.h + (row0 + m) * FF + c, gelu_erf4(z));
+            STORE_HANDOFF(o.h + (row0 + m) * FF + c, gelu_erf4(z));
           }
         }
       }

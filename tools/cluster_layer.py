@@ -14,6 +14,7 @@ dev = torch.device("cuda")
 def build():
     so = "/tmp/libcluster_layer.so"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                           "-DXCD_LOCAL=%d" % int(os.environ.get("XCD_LOCAL", "0")),
                            os.path.join(ROOT, "tools", "cluster_layer.hip"), "-o", so])
     lib = ctypes.CDLL(so)
     lib.cl_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]

@@ -17,8 +17,11 @@ __device__ __forceinline__ unsigned ld_rlx(const unsigned* p) { return __hip_ato
 __device__ __forceinline__ void st_rlx(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // mode 0: cluster = 4 consecutive workgroup ids (four different XCDs under round-robin placement); 1: same id % 8 (one XCD)
+// LOCAL: the cluster shares one XCD's L2, which is coherent for its own CUs: plain stores (they stay in L2), loads that only skip the
+// CU's L1 (sc0) -- correct ONLY if the four workgroups really are on one XCD (checked with the XCC_ID register)
+template <bool LOCAL>
 __global__ __launch_bounds__(512) void handoff(char* slices, unsigned* flags, unsigned* status, int slice_bytes, int rounds, int mode,
-                                               unsigned long long* t_out) {
+                                               unsigned long long* t_out, unsigned* xcc) {
   const int b = blockIdx.x;
   int cluster, member;
   if (mode == 0) { cluster = b >> 2; member = b & 3; }
@@ -31,13 +34,18 @@ __global__ __launch_bounds__(512) void handoff(char* slices, unsigned* flags, un
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slices, 0, 0x7fffffff, 0x00020000);
   const int chunks = slice_bytes / 16;
   unsigned bad = 0;
+  if (threadIdx.x == 0) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    xcc[wg] = x & 15u;
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (int r = 0; r < rounds; ++r) {
     const unsigned epoch = (unsigned)r + 1;
     const int64_t mine = ((int64_t)(r & 1) * 1024 + wg) * slice_bytes;
     for (int c = threadIdx.x; c < chunks; c += 512) {
       const u32x4 v = {epoch, (unsigned)wg, (unsigned)c, epoch ^ (unsigned)c};
-      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(mine + (int64_t)c * 16), 0, 16);  // aux 16 = sc1: write-through
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(mine + (int64_t)c * 16), 0, LOCAL ? 0 : 16);  // aux 16 = sc1: write-through
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
     __syncthreads();
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(512) void handoff(char* slices, unsigned* flags, un
       const int peer = cluster * 4 + ((member + p) & 3);
       const int64_t theirs = ((int64_t)(r & 1) * 1024 + peer) * slice_bytes;
       for (int c = threadIdx.x; c < chunks; c += 512) {
-        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(theirs + (int64_t)c * 16), 0, 16));
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(theirs + (int64_t)c * 16), 0, LOCAL ? 1 : 16));
         bad |= (v[0] != epoch) | (v[1] != (unsigned)peer) | (v[2] != (unsigned)c) | (v[3] != (epoch ^ (unsigned)c));
       }
     }
@@ -75,17 +83,24 @@ int main() {
   char* slices; unsigned *flags, *status; unsigned long long* t_out;
   CK(hipMalloc(&slices, 2ll * 1024 * 131072)); CK(hipMalloc(&flags, 1024 * 32 * 4)); CK(hipMalloc(&status, 64)); CK(hipMalloc(&t_out, 256 * 8));
   std::vector<unsigned long long> t(256);
-  for (int mode = 0; mode < 2; ++mode)
+  unsigned* xcc; CK(hipMalloc(&xcc, 1024 * 4));
+  std::vector<unsigned> hx(256);
+  for (int mode = 0; mode < 3; ++mode)
     for (int bytes : {1024, 32768, 131072}) {
       CK(hipMemset(flags, 0, 1024 * 32 * 4)); CK(hipMemset(status, 0, 64));
-      hipLaunchKernelGGL(handoff, dim3(256), dim3(512), 0, 0, slices, flags, status, bytes, rounds, mode, t_out);
+      if (mode == 2) hipLaunchKernelGGL(handoff<true>, dim3(256), dim3(512), 0, 0, slices, flags, status, bytes, rounds, 1, t_out, xcc);
+      else hipLaunchKernelGGL(handoff<false>, dim3(256), dim3(512), 0, 0, slices, flags, status, bytes, rounds, mode, t_out, xcc);
       CK(hipDeviceSynchronize());
       unsigned st[2]; CK(hipMemcpy(st, status, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(t.data(), t_out, 256 * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hx.data(), xcc, 256 * 4, hipMemcpyDeviceToHost));
+      int split = 0;   // clusters whose four members are NOT on one XCD
+      for (int c = 0; c < 64; ++c) split += !(hx[4 * c] == hx[4 * c + 1] && hx[4 * c] == hx[4 * c + 2] && hx[4 * c] == hx[4 * c + 3]);
       unsigned long long mx = 0; double mean = 0;
       for (auto v : t) { mx = v > mx ? v : mx; mean += (double)v; }
       mean /= 256;
-      printf("cluster of 4 on %s, slice %6d B: %.2f us per round (mean over workgroups; slowest %.2f)  timeout word 0x%x  mismatches %u\n",
-             mode ? "ONE XCD  " : "four XCDs", bytes, mean / 100.0 / rounds, (double)mx / 100.0 / rounds, st[0], st[1]);
+      printf("cluster of 4 on %s, slice %6d B: %.2f us per round (mean over workgroups; slowest %.2f)  timeout word 0x%x  mismatches %u  clusters split over XCDs %d\n",
+             mode == 0 ? "four XCDs" : mode == 1 ? "ONE XCD  " : "ONE XCD, through its L2 (plain stores, sc0 loads)", bytes, mean / 100.0 / rounds,
+             (double)mx / 100.0 / rounds, st[0], st[1], split);
     }
   return 0;
 }
