@@ -1146,13 +1146,13 @@ __global__ __launch_bounds__(XL_THREADS) void gemm_xl_kernel(const T* __restrict
     // Issuing a wave's eight 1-KiB DMA pieces takes it ~0.4 us during which it multiplies nothing (one wave sustains
     // ~20 GB/s of LDS-DMA, profiles/r01_lds_fill_probe.txt).  Waves w and w+4 share a SIMD: the first issues before its
     // MFMAs, the second between its two K steps, so each SIMD always has one wave multiplying.
-    const bool issue_now = (t + 1 < nt);
+    const bool issue_now = (t + 1 < nt) && !(ep.dbg & 2);
     if (issue_now && (wave < 4 || (ep.dbg & 64))) issue((t + 1) & 1, t + 1);
     if (t == 0) IMT_STAMP(ep.trace, 1);
     const char* st = smem + (t & 1) * XL_STAGE;
-    compute_tile_xl<T, LAYOUT, 0>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
+    if (!(ep.dbg & 1)) compute_tile_xl<T, LAYOUT, 0>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
     if (issue_now && wave >= 4 && !(ep.dbg & 64)) issue((t + 1) & 1, t + 1);
-    compute_tile_xl<T, LAYOUT, 1>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
+    if (!(ep.dbg & 1)) compute_tile_xl<T, LAYOUT, 1>(acc, st + wmi * TILE_BYTES, st + (2 + (wni >> 1)) * TILE_BYTES, wn);
     if (LAYOUT == IMT_TN && do_colsum) cs.add_tile(st + half * TILE_BYTES, ht);
   }
   const float alpha = ep.alpha_dev ? ep.alpha * ep.alpha_dev[0] : ep.alpha;
