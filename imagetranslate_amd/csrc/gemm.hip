@@ -1058,8 +1058,9 @@ IMT_DEVICE void epilogue_xl_direct(const f32x4 (&acc)[8][4], int mw, int nw, int
         const f32x4 z = Vec4<T>::cvt(zr[i & 1][j]);
         v *= gelu_erf_grad4(z);
       }
-      if (live) {
+      if (live && !(ep.dbg & 128)) {  // dbg bit 7 (tuning only): no output stores -- what the stores and their write-back cost
         if (C_F32) Vec4<float>::store(reinterpret_cast<float*>(ep.C) + m * ep.ldc + n, v);
+        else if (ep.dbg & 256) Vec4<T>::store_wt(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);  // bit 8: write-through stores
         else       Vec4<T>::store(reinterpret_cast<T*>(ep.C) + m * ep.ldc + n, v);
       }
     }

@@ -22,4 +22,6 @@ def t(lay, M, N, K, fg, reps=30):
 for lay, M, N, K in [(O.IMT_NT, 8192, 2048, 512), (O.IMT_NT, 8192, 2048, 2048), (O.IMT_NT, 8192, 2048, 8192)]:
     full, nomma, nodma = t(lay, M, N, K, 6), t(lay, M, N, K, 106), t(lay, M, N, K, 206)
     nt = K // 64
+    nost, wt = t(lay, M, N, K, 12806), t(lay, M, N, K, 25606)
+    print("   no output stores %.1f us | write-through stores %.1f us" % (nost, wt))
     print("NT %d x %d x %d: full %.1f us | DMA only %.1f | MFMA only %.1f   (per 64-deep K tile: %.2f / %.2f / %.2f us incl. fixed parts)" % (M, N, K, full, nomma, nodma, full / nt, nomma / nt, nodma / nt), flush=True)
