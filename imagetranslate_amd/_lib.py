@@ -212,6 +212,7 @@ SIGNATURES = {
     "imt_decode_cross_bytes": (c_int64, [POINTER(StackDesc), c_int, c_int]),
     "imt_decode_begin": (c_int, [POINTER(StackDesc), _P, c_int, c_int, _P, _P]),
     "imt_decode_step": (c_int, [POINTER(StackDesc), POINTER(DecodeIO), _P, c_int64, _P]),
+    "imt_decode_check": (c_int, [POINTER(StackDesc), c_int, _P, _P]),
     "imt_beam_step": (c_int, [POINTER(BeamArgs), _P]),
     "imt_select_plan": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
     "imt_mass_mask": (c_int, [POINTER(MassArgs), _P]),

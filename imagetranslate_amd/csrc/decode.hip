@@ -2,119 +2,9 @@
 // step (log-softmax + length-penalised top-k + the reference's bookkeeping, src/seq_gen.py:193-227).
 // Both are HBM/latency-bound byte and index work: no MFMA here, only coalesced 16-byte row reads.
 #include "common.hpp"
+#include "decode_attn.hpp"
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------ attention
-// One wave per (hypothesis, head).  A key/value row of the head is DH elements = DH/8 lanes x 8 elements (16 B for
-// bf16), so a wave streams 64/(DH/8) keys per iteration with fully coalesced row segments.  Each lane group keeps
-// its own running (max, sum, o[8]) -- online softmax -- and the groups are merged once at the end.
-template <typename T> IMT_DEVICE void load8(const T* p, float (&v)[8]);
-template <> IMT_DEVICE void load8<float>(const float* p, float (&v)[8]) {
-  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
-}
-template <> IMT_DEVICE void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
-  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
-}
-template <typename T> IMT_DEVICE void store8(T* p, const float (&v)[8]);
-template <> IMT_DEVICE void store8<float>(float* p, const float (&v)[8]) {
-  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-  *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
-}
-template <> IMT_DEVICE void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-  bf16x8 a;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) a[e] = (bf16_t)v[e];
-  *reinterpret_cast<bf16x8*>(p) = a;
-}
-
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_decode_kernel(imt_attn_decode_args a) {
-  constexpr int CH = DH / 8;    // lanes per key row
-  constexpr int G = 64 / CH;    // keys in flight per wave
-  const int lane = threadIdx.x & 63;
-  const int w = imt_xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
-  if (w >= a.R * a.H) return;
-  const int r = w / a.H, h = w % a.H;
-  const int c = lane % CH, g = lane / CH;
-  const int sent = r / a.rep;
-  float q[8];
-  load8<T>(reinterpret_cast<const T*>(a.Q) + (int64_t)r * a.ldq + h * DH + 8 * c, q);
-  const T* Kb = reinterpret_cast<const T*>(a.K) + h * DH + 8 * c;
-  const T* Vb = reinterpret_cast<const T*>(a.V) + h * DH + 8 * c;
-  float m = -INFINITY, l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  // UNR key groups per iteration: their slot lookups, then their K/V row segments, are all in flight before the first
-  // dependent softmax update (one group per iteration was a chain of exposed load latencies: 18.7 us at 145 keys)
-  constexpr int UNR = 4;
-  for (int j0 = 0; j0 < a.n_keys; j0 += G * UNR) {
-    float k[UNR][8], v[UNR][8];
-    int jj[UNR];
-    int64_t off[UNR];
-    uint8_t mk[UNR];
-    // slot and mask lookups are unconditional loads (an absent table reads a valid stand-in address and the value is
-    // replaced by a select): a load under a branch drains vmcnt at the join, and the mask byte used to be fetched
-    // inside the dependent softmax chain below -- one exposed latency per key group
-    const int32_t* slot_p = a.slots ? a.slots + (int64_t)r * a.ld_slots : reinterpret_cast<const int32_t*>(a.Q);
-    const uint8_t* mask_p = a.key_mask ? a.key_mask + (int64_t)sent * a.ld_mask : reinterpret_cast<const uint8_t*>(a.Q);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int j = j0 + u * G + g;
-      jj[u] = j < a.n_keys ? j : a.n_keys - 1;
-      const int32_t sv = slot_p[a.slots ? jj[u] : 0];
-      mk[u] = mask_p[a.key_mask ? jj[u] : 0];
-      const int64_t row = a.slots ? (int64_t)sv : (int64_t)sent;
-      off[u] = row * a.ld_row + (int64_t)jj[u] * a.ld_pos;
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      load8<T>(Kb + off[u], k[u]);
-      load8<T>(Vb + off[u], v[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const bool valid = j0 + u * G + g < a.n_keys;
-      float s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(q[e], k[u][e], s);
-#pragma unroll
-      for (int x = 1; x < CH; x <<= 1) s += __shfl_xor(s, x, 64);
-      s *= a.scale;
-      if (a.key_mask && !mk[u]) s += -10000.0f;
-      if (valid) {
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn), p = __expf(s - mn);  // exp(-inf) == 0 on the first key
-        l = l * corr + p;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(p, v[u][e], o[e] * corr);
-        m = mn;
-      }
-    }
-  }
-  // merge the G lane groups (lanes with equal c)
-  float M = m;
-#pragma unroll
-  for (int x = CH; x < 64; x <<= 1) M = fmaxf(M, __shfl_xor(M, x, 64));
-  const float f = (m == -INFINITY) ? 0.f : __expf(m - M);
-  l *= f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] *= f;
-#pragma unroll
-  for (int x = CH; x < 64; x <<= 1) {
-    l += __shfl_xor(l, x, 64);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], x, 64);
-  }
-  if (g == 0) {
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] *= inv;
-    store8<T>(reinterpret_cast<T*>(a.O) + (int64_t)r * a.ldo + h * DH + 8 * c, o);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------ beam step
 // (score desc, index asc) ordering: a "better" than b

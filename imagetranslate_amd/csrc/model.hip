@@ -5,6 +5,7 @@
 // so the whole forward/backward is capturable in a hipGraph.  Activations needed by backward are kept in the
 // caller-owned workspace, carved identically by forward and backward.
 #include "common.hpp"
+#include "decode_fused.hpp"
 
 namespace {
 
@@ -561,8 +562,14 @@ namespace {
 struct DecodeWs {
   void* emb_sum; void* x; void* ctx; void* pre_ln; void* a; void* q; void* b; void* h; void* z; float* mean; float* rstd;
   void* splitk; int64_t splitk_bytes;  // imt_gemm's split-K slabs (R rows: a handful of output tiles per product)
+  char* fused; int64_t fused_layer_bytes; unsigned* fused_bar;  // one-launch step (decode_fused.hip): per-layer hand-off buffers, barrier words
   int64_t bytes;
 };
+
+// the one-launch decoder step is built for the BASELINE shape family: bf16, hidden size 512 in heads of 64, ff a multiple of 512
+bool fused_decode_shape(const imt_stack_desc* m) {
+  return m->dtype == IMT_BF16 && m->d == IMT_FUSED_D && m->heads * 64 == m->d && m->ff % 512 == 0 && m->ff >= 512 && m->n_layers <= IMT_FUSED_MAX_LAYERS;
+}
 
 void carve_decode(const imt_stack_desc* m, int r_max, void* ws, DecodeWs& w) {
   Carver c(ws);
@@ -573,6 +580,12 @@ void carve_decode(const imt_stack_desc* m, int r_max, void* ws, DecodeWs& w) {
   w.mean = (float*)c.take(R * 4); w.rstd = (float*)c.take(R * 4);
   w.splitk_bytes = imt_gemm_splitk_ws_bytes();
   w.splitk = c.take(w.splitk_bytes);
+  w.fused = nullptr; w.fused_layer_bytes = 0; w.fused_bar = nullptr;
+  if (fused_decode_shape(m)) {
+    w.fused_layer_bytes = (imt_decode_fused_layer_bytes(r_max, m->d, m->ff) + 255) & ~(int64_t)255;
+    w.fused = (char*)c.take(w.fused_layer_bytes * m->n_layers);
+    w.fused_bar = (unsigned*)c.take(IMT_FUSED_BAR_WORDS * sizeof(unsigned));
+  }
   w.bytes = c.off;
 }
 
@@ -622,6 +635,25 @@ extern "C" int imt_decode_begin(const imt_stack_desc* m, const void* enc_states,
   return IMT_OK;
 }
 
+extern "C" int imt_decode_check(const imt_stack_desc* m, int r_max, const void* ws, void* stream) {
+  RC(validate_decoder(m));
+  IMT_CHECK_ARG(ws && r_max > 0, "decode_check: bad arguments");
+  DecodeWs w;
+  carve_decode(m, r_max, const_cast<void*>(ws), w);
+  if (!w.fused || !imt_decode_fused_enabled()) return IMT_OK;
+  unsigned status = 0;
+  if (hipMemcpyAsync(&status, w.fused_bar + IMT_FUSED_BAR_WORDS - 1, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    imt_set_error("decode_check: cannot read the status word");
+    return IMT_ERR_LAUNCH;
+  }
+  if (status != 0) {
+    imt_set_error("decode: a one-launch decoder step was abandoned (grid barrier %u timed out); its tokens are not valid", status & 0xfffu);
+    return IMT_ERR_LAUNCH;
+  }
+  return IMT_OK;
+}
+
 extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io, void* ws, int64_t ws_bytes, void* stream) {
   RC(validate_decoder(m));
   IMT_CHECK_ARG(io, "decode_step: null io");
@@ -641,6 +673,38 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
   const int64_t cross_layer = (int64_t)B * io->Tk * 2 * d;
   RC(imt_embed_ln_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), c.P(m->emb_ln_g),
                       c.P(m->emb_ln_b), w.emb_sum, w.x, w.mean, w.rstd, R, 1, d, m->vocab, m->max_pos, m->n_types, m->ln_eps, 0.f, 0, c.st));
+  if (w.fused && imt_decode_fused_enabled()) {
+    // one launch for the whole stack (decode_fused.hip); the per-operator chain below stays for fp32 and other shapes
+    ImtFusedArgs f;
+    memset(&f, 0, sizeof(f));
+    const bf16_t* P = reinterpret_cast<const bf16_t*>(m->params);
+    for (int l = 0; l < m->n_layers; ++l) {
+      const imt_layer_desc& p = m->layers[l];
+      ImtFusedLayer& L = f.L[l];
+      L.wqkv = P + p.self_attn.qkv_w; L.bqkv = P + p.self_attn.qkv_b; L.wo = P + p.self_attn.o_w; L.bo = P + p.self_attn.o_b;
+      L.g1 = P + p.self_attn.ln_g; L.b1 = P + p.self_attn.ln_b;
+      L.wq = P + p.cross_attn.qkv_w; L.bq = P + p.cross_attn.qkv_b; L.wo2 = P + p.cross_attn.o_w; L.bo2 = P + p.cross_attn.o_b;
+      L.g2 = P + p.cross_attn.ln_g; L.b2 = P + p.cross_attn.ln_b;
+      L.w1 = P + p.ff1_w; L.bf1 = P + p.ff1_b; L.w2 = P + p.ff2_w; L.bf2 = P + p.ff2_b; L.g3 = P + p.ln2_g; L.b3 = P + p.ln2_b;
+      L.cache = reinterpret_cast<bf16_t*>(offp(io->self_cache, l * self_layer, c.es));
+      L.cross_kv = reinterpret_cast<const bf16_t*>(offp(io->cross_kv, l * cross_layer, c.es));
+      Carver fc(w.fused + l * w.fused_layer_bytes);
+      const int64_t rm = io->r_max;
+      L.xin = (bf16_t*)fc.take(rm * d * 2); L.ctx1 = (bf16_t*)fc.take(rm * d * 2); L.a = (bf16_t*)fc.take(rm * d * 2);
+      L.q = (bf16_t*)fc.take(rm * d * 2); L.ctx2 = (bf16_t*)fc.take(rm * d * 2); L.b = (bf16_t*)fc.take(rm * d * 2);
+      L.h = (bf16_t*)fc.take(rm * ff * 2);
+      L.pre1 = (float*)fc.take(rm * d * 4); L.pre2 = (float*)fc.take(rm * d * 4); L.pre3 = (float*)fc.take(rm * d * 4);
+    }
+    f.n_layers = m->n_layers; f.R = R; f.rep = io->rep; f.pos = io->pos; f.Tk = io->Tk; f.t_max = io->t_max; f.r_max = io->r_max;
+    f.H = H; f.dh = dh; f.ff = ff;
+    f.x0 = reinterpret_cast<const bf16_t*>(w.x); f.out = reinterpret_cast<bf16_t*>(io->out);
+    f.slots = io->slots; f.enc_mask = io->enc_mask; f.eps = m->ln_eps; f.bar = w.fused_bar;
+    if (io->pos == 0 && hipMemsetAsync(w.fused_bar + IMT_FUSED_BAR_WORDS - 1, 0, sizeof(unsigned), c.st) != hipSuccess) {
+      imt_set_error("decode_step: memset failed");   // a new search: clear the sticky status word
+      return IMT_ERR_LAUNCH;
+    }
+    return imt_decode_fused_launch(f, c.st);
+  }
   const void* x = w.x;
   for (int l = 0; l < m->n_layers; ++l) {
     const imt_layer_desc& p = m->layers[l];

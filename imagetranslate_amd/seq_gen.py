@@ -223,6 +223,8 @@ class BeamDecoder(nn.Module):
                     done_at = int(full[0, 0]) + 1
         if done_at is not None and done_at >= 1:
             n_cols = min(n_cols, done_at + 1)
+        if inc is not None:
+            inc.check()   # raises if a one-launch decoder step was abandoned (bounded waits); one sync, the outputs are read next anyway
         outputs = st.hist[st.cur].view(B, beam, t_max)[:, 0, :n_cols]
         if unpad_output:
             return get_outputs_until_eos(eos, outputs, size_limit=max_lens_host)
@@ -269,3 +271,8 @@ class _Incremental:
         io.self_cache, io.cross_kv, io.out = self.cache.data_ptr(), self.cross.data_ptr(), out.data_ptr()
         L.check(self.lib.imt_decode_step(ctypes.byref(self.desc), ctypes.byref(io), ctypes.c_void_p(self.ws.data_ptr()),
                                          self.ws_bytes, self.stream), "imt_decode_step")
+
+    def check(self):
+        """End of a search: did every one-launch step run to its end (include/imt_hip.h: imt_decode_check)?  Synchronises."""
+        L.check(self.lib.imt_decode_check(ctypes.byref(self.desc), self.r_max, ctypes.c_void_p(self.ws.data_ptr()), self.stream),
+                "imt_decode_check")

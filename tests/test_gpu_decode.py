@@ -345,3 +345,73 @@ def test_beam_first_step_against_reference_beam_decoder(cuda, name, kv_cache):
     toks = dec(pad_idx=0, max_len=2, **inp)
     padded = dec(pad_idx=0, max_len=2, unpad_output=False, **inp)
     check_beam_step1(case, toks, padded, None, inp["first_tokens"])
+
+
+@pytest.mark.parametrize("layers,B,beam,Tk", [(2, 7, 5, 40), (6, 64, 5, 128), (2, 3, 1, 9), (2, 5, 3, 21), (1, 9, 4, 150), (2, 4, 2, 64), (1, 6, 7, 33)])
+def test_one_launch_decoder_step_matches_the_per_operator_chain(cuda, monkeypatch, layers, B, beam, Tk):
+    """csrc/decode_fused.hip (bf16, hidden size 512: ONE launch per decoding step, grid-wide barriers between its phases)
+    against the launch-per-operator chain of imt_decode_step on the same weights, tokens, slot tables and caches: hidden
+    states of every step and the q|k|v written into the cache.  Both compute in bf16 with fp32 accumulation; they differ in
+    where a pre-LayerNorm sum is rounded, hence the tolerance.  Row counts that are not multiples of the 32-row items, a
+    padded encoder mask and shuffled slot tables (beam re-ordering) are covered; imt_decode_check must report a clean run."""
+    import imagetranslate_amd.seq2seq as S
+    from imagetranslate_amd import _lib as L
+    from imagetranslate_amd.param_store import store_of
+    from imagetranslate_amd.seq_gen import _Incremental
+    torch.manual_seed(5)
+    tp = R.SyntheticTextProcessor(1000)
+    ours = S.Seq2Seq(tp, lang_dec=False, enc_layer=1, dec_layer=layers, embed_dim=512, intermediate_dim=2048, num_attention_heads=8)
+    for p in ours.parameters():   # biases and LayerNorm parameters away from their (0, 1) initial values
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    ours = ours.cuda().eval()
+    ours.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(1)
+    enc = torch.randn(B, Tk, 512, generator=g).cuda().bfloat16().contiguous()
+    mask = torch.ones(B, Tk, dtype=torch.uint8)
+    for b in range(B):
+        mask[b, Tk - (b % 4):] = 0
+    mask = mask.cuda()
+    T, rows_max = 6, B * beam
+    store = store_of(ours.decoder).ensure()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    toks = torch.randint(6, 1000, (T, rows_max), generator=g).cuda()
+    types = torch.ones(rows_max, dtype=torch.long).cuda()
+    # slot tables: at step t row r reads position j < t from cache row slots[t][r, j] (any row of the same sentence), position t from itself
+    slot_tabs = []
+    for t in range(T):
+        rep = 1 if t == 0 else beam
+        rows = B * rep
+        tab = torch.zeros(rows_max, T, dtype=torch.int32)
+        for r in range(rows):
+            sent = r // rep
+            for j in range(T):
+                prev_rep = 1 if j == 0 else beam
+                tab[r, j] = r if j >= t else sent * prev_rep + int(torch.randint(0, prev_rep, (1,), generator=g))
+        slot_tabs.append(tab.cuda())
+    runs = {}
+    for mode in ("fp32", "0", "1"):   # fp32 per-operator chain (the yardstick), bf16 per-operator chain, bf16 one launch
+        dt = torch.float32 if mode == "fp32" else torch.bfloat16
+        ours.set_compute_dtype(dt)
+        monkeypatch.setenv("IMT_DECODE_FUSED", "1" if mode == "1" else "0")
+        inc = _Incremental(L.load(), ours.decoder, store, dt, store.params_for(dt), enc.to(dt), mask, B, beam, T, st)
+        inc.cache.zero_()
+        outs = []
+        for t in range(T):
+            rep = 1 if t == 0 else beam
+            rows = B * rep
+            out = torch.zeros(rows_max, 512, device="cuda", dtype=dt)
+            inc.step(t, rows, rep, toks[t, :rows].contiguous(), types[:rows].contiguous(), slot_tabs[t], out)
+            outs.append(out[:rows].float().clone())
+        inc.check()
+        torch.cuda.synchronize()
+        runs[mode] = (outs, inc.cache.view(dt).float().clone())
+    from tests.util import rel_err
+    for t in range(T):
+        one, chain, truth = runs["1"][0][t], runs["0"][0][t], runs["fp32"][0][t]
+        assert torch.isfinite(one).all()
+        e_one, e_chain = rel_err(one, truth), rel_err(chain, truth)
+        assert e_one <= max(1e-2, 1.5 * e_chain), "step %d: one launch %.2e from the fp32 chain, the bf16 chain %.2e" % (t, e_one, e_chain)
+        assert_close(one, chain, 6e-2, "hidden states of step %d (%d layers, %d rows)" % (t, layers, one.shape[0]))
+    e_one, e_chain = rel_err(runs["1"][1], runs["fp32"][1]), rel_err(runs["0"][1], runs["fp32"][1])
+    assert e_one <= max(1e-2, 1.5 * e_chain), "self-attention cache: one launch %.2e from fp32, the bf16 chain %.2e" % (e_one, e_chain)

@@ -39,7 +39,11 @@ def main():
     for r in sorted(rows[:n], key=lambda r: -r.total_ms):
         print("  %-28s %6d launches %8.3f ms  (%.1f us each)" % (r.kind.decode(), r.launches, r.total_ms, 1e3 * r.total_ms / r.launches))
     print("  total %.3f ms" % sum(r.total_ms for r in rows[:n]), flush=True)
-    for kv, max_len in ((True, None), (False, None)):
+    import os
+    for kv, max_len, fused in ((True, None, "1"), (True, None, "0"), (False, None, "0")):
+        if kv:
+            print("IMT_DECODE_FUSED=%s (1: one launch per decoder step, 0: the launch-per-operator chain)" % fused)
+        os.environ["IMT_DECODE_FUSED"] = fused
         dec = BeamDecoder(model, beam_width=beam, kv_cache=kv)
         out = dec(max_len=8, **args)  # warm-up
         torch.cuda.synchronize()
