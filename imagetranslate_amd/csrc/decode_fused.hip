@@ -26,7 +26,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int FD = IMT_FUSED_D, BR = 32, FTHREADS = 1024, FWAVES = FTHREADS / 64, CHUNK = 512;
 // 16 waves per workgroup: the attention phases are one wave per (hypothesis, head) -- 2560 of them at 64 x 5 x 8 -- and latency-bound, so they
 // want every wave slot of the chip (4096); the products use waves 0-3 for the MFMAs and all 16 for staging.
-constexpr int FUSED_UNR = 6;   // key groups in flight per attention wave (8 spills at 128 registers)
+constexpr int FUSED_UNR = 5;   // key groups in flight per attention wave (6 and 8 spill at the 128 registers of 16 waves per CU)
 constexpr int W_REGION = 65536, A_REGION = 65536, F_LDS = W_REGION + A_REGION;
 constexpr int A_SLOT = BR * CHUNK * 2;  // 32 KiB: [8 sub-tiles][32 rows][64 k]
 
@@ -130,10 +130,32 @@ struct GP {
   const T* W; const T* bias; int N, K;              // W [N][K]; K a multiple of 512
   const T* A; int64_t lda;                          // AMODE 0: bf16 rows [R][lda]
   const float* pre; const T *gamma, *beta; T* norm_out;  // AMODE 1: LayerNorm of fp32 rows [R][512]; column tile 0 stores norm_out
+  // AMODE 2: LayerNorm of word + position + type embedding rows (gamma / beta / norm_out as above)
+  const int64_t *ids, *pos_ids, *type_ids; const T *emb_word, *emb_pos, *emb_type; int vocab, max_pos, n_types;
   T* out; int64_t ldo;                              // EMODE 0 / 2: bf16 (+ GELU)
   float* pre_out; const T* resid; bool resid_sc1;   // EMODE 1: fp32 acc + bias + resid -> pre_out [R][512]
 };
 
+// word + position + type embedding of hypothesis row `grow` (8 columns per lane); indices clamped like imt_embed_ln_fwd; the sum is rounded
+// to bf16 before the LayerNorm, as that kernel stores it
+IMT_DEVICE RowRaw emb_request(const GP& p, int grow, int R) {
+  const int lane = threadIdx.x & 63;
+  const int rr = min(grow, R - 1);
+  int64_t wi = p.ids[rr], pi = p.pos_ids[rr], ti = p.type_ids ? p.type_ids[rr] : 0;
+  if (wi < 0 || wi >= p.vocab) wi = 0;
+  if (pi < 0 || pi >= p.max_pos) pi = 0;
+  if (ti < 0 || ti >= p.n_types) ti = 0;
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p.emb_word + wi * FD + 8 * lane);
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(p.emb_pos + pi * FD + 8 * lane);
+  const bf16x8 c = *reinterpret_cast<const bf16x8*>(p.emb_type + ti * FD + 8 * lane);
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = (float)(bf16_t)(((float)a[e] + (float)b[e]) + (float)c[e]);
+  RowRaw r;
+  r.a = __builtin_bit_cast(u32x4, f32x4{x[0], x[1], x[2], x[3]});
+  r.b = __builtin_bit_cast(u32x4, f32x4{x[4], x[5], x[6], x[7]});
+  return r;
+}
 // BRT rows x (32 NCT) columns on BRT / 8 waves: wave -> row tile wave % (BRT / 16), NCT column tiles from (wave / (BRT / 16)) NCT
 template <int BRT, int NCT>
 IMT_DEVICE void mma_chunk(const char* A, const char* W, f32x4 (&acc)[NCT]) {
@@ -172,7 +194,7 @@ IMT_DEVICE void gemm_phase(const GP& g, int R, float eps, char* smem, bool w_rea
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nct = g.N / BC, nitems = ((R + BRT - 1) / BRT) * nct, nch = g.K / CHUNK;
   const __amdgpu_buffer_rsrc_t rsW = rsrc_of(g.W, (int64_t)g.N * g.K * 2);
-  const __amdgpu_buffer_rsrc_t rsA = AMODE == 0 ? rsrc_of(g.A, (int64_t)R * g.lda * 2) : rsrc_of(g.pre, (int64_t)R * FD * 4);
+  const __amdgpu_buffer_rsrc_t rsA = AMODE == 0 ? rsrc_of(g.A, (int64_t)R * g.lda * 2) : rsrc_of(AMODE == 1 ? (const void*)g.pre : (const void*)g.W, (int64_t)R * FD * 4);
   char* Wreg = smem;
   char* Areg = smem + W_REGION;
   bool first = true;
@@ -188,7 +210,8 @@ IMT_DEVICE void gemm_phase(const GP& g, int R, float eps, char* smem, bool w_rea
       load_gamma_beta(g.gamma, g.beta, gm, be);
       RowRaw raw[BRT / FWAVES];
 #pragma unroll
-      for (int rr = 0; rr < BRT / FWAVES; ++rr) raw[rr] = ln_request(rsA, row0 + wave * (BRT / FWAVES) + rr);
+      for (int rr = 0; rr < BRT / FWAVES; ++rr)
+        raw[rr] = AMODE == 2 ? emb_request(g, row0 + wave * (BRT / FWAVES) + rr, R) : ln_request(rsA, row0 + wave * (BRT / FWAVES) + rr);
 #pragma unroll
       for (int rr = 0; rr < BRT / FWAVES; ++rr) {
         const int row = wave * (BRT / FWAVES) + rr;
@@ -275,15 +298,16 @@ __global__ __launch_bounds__(FTHREADS) void decode_fused_kernel(ImtFusedArgs p) 
     g = GP{};
     g.W = L.wqkv; g.bias = L.bqkv; g.N = 3 * d; g.K = d; g.out = L.cache + (int64_t)p.pos * 3 * d; g.ldo = row3;
     if (l == 0) {
-      g.A = p.x0; g.lda = d;
-      gemm_phase<32, 2, 0, 0>(g, R, p.eps, smem, w_ready);
+      g.ids = p.ids; g.pos_ids = p.pos_ids; g.type_ids = p.type_ids; g.emb_word = p.emb_word; g.emb_pos = p.emb_pos; g.emb_type = p.emb_type;
+      g.vocab = p.vocab; g.max_pos = p.max_pos; g.n_types = p.n_types; g.gamma = p.emb_g; g.beta = p.emb_b; g.norm_out = L.xin;
+      gemm_phase<32, 2, 2, 0>(g, R, p.eps, smem, w_ready);
     } else {
       g.pre = p.L[l - 1].pre3; g.gamma = p.L[l - 1].g3; g.beta = p.L[l - 1].b3; g.norm_out = L.xin;
       gemm_phase<32, 2, 1, 0>(g, R, p.eps, smem, w_ready);
     }
-    const T* x_in = l == 0 ? p.x0 : L.xin;
+    const T* x_in = L.xin;   // layer input: the embedding LayerNorm (l == 0) or the previous layer's output LayerNorm, stored by P1's column tile 0
     GP g3{};
-    g3.W = L.wo; g3.bias = L.bo; g3.N = d; g3.K = d; g3.A = L.ctx1; g3.lda = d; g3.pre_out = L.pre1; g3.resid = x_in; g3.resid_sc1 = l > 0;
+    g3.W = L.wo; g3.bias = L.bo; g3.N = d; g3.K = d; g3.A = L.ctx1; g3.lda = d; g3.pre_out = L.pre1; g3.resid = x_in; g3.resid_sc1 = true;
     __syncthreads();
     prefetch_w<32, 1>(g3, R, smem);   // the weights of P3 travel under the barrier and the self attention
     if (!bar.sync()) return;

@@ -21,7 +21,10 @@ struct ImtFusedLayer {
 struct ImtFusedArgs {
   ImtFusedLayer L[IMT_FUSED_MAX_LAYERS];
   int n_layers, R, rep, pos, Tk, t_max, r_max, H, dh, ff;
-  const bf16_t* x0;        // [R][d] embedding LayerNorm output
+  // BertEmbeddings of the newest tokens, computed while layer 0 stages its operand: word[ids] + pos[pos_ids] + type[type_ids] -> LayerNorm
+  const int64_t *ids, *pos_ids, *type_ids;   // [R]; type_ids nullable (zeros)
+  const bf16_t *emb_word, *emb_pos, *emb_type, *emb_g, *emb_b;
+  int vocab, max_pos, n_types;
   bf16_t* out;             // [R][d]
   const int32_t* slots; const uint8_t* enc_mask;
   float eps;

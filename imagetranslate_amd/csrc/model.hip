@@ -671,8 +671,6 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
   const int64_t self_layer = (int64_t)io->r_max * row3;
   const int B = R / io->rep;
   const int64_t cross_layer = (int64_t)B * io->Tk * 2 * d;
-  RC(imt_embed_ln_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), c.P(m->emb_ln_g),
-                      c.P(m->emb_ln_b), w.emb_sum, w.x, w.mean, w.rstd, R, 1, d, m->vocab, m->max_pos, m->n_types, m->ln_eps, 0.f, 0, c.st));
   if (w.fused && imt_decode_fused_enabled()) {
     // one launch for the whole stack (decode_fused.hip); the per-operator chain below stays for fp32 and other shapes
     ImtFusedArgs f;
@@ -697,7 +695,10 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
     }
     f.n_layers = m->n_layers; f.R = R; f.rep = io->rep; f.pos = io->pos; f.Tk = io->Tk; f.t_max = io->t_max; f.r_max = io->r_max;
     f.H = H; f.dh = dh; f.ff = ff;
-    f.x0 = reinterpret_cast<const bf16_t*>(w.x); f.out = reinterpret_cast<bf16_t*>(io->out);
+    f.ids = io->ids; f.pos_ids = io->pos_ids; f.type_ids = io->type_ids;
+    f.emb_word = P + m->emb_word; f.emb_pos = P + m->emb_pos; f.emb_type = P + m->emb_type; f.emb_g = P + m->emb_ln_g; f.emb_b = P + m->emb_ln_b;
+    f.vocab = m->vocab; f.max_pos = m->max_pos; f.n_types = m->n_types;
+    f.out = reinterpret_cast<bf16_t*>(io->out);
     f.slots = io->slots; f.enc_mask = io->enc_mask; f.eps = m->ln_eps; f.bar = w.fused_bar;
     if (io->pos == 0 && hipMemsetAsync(w.fused_bar + IMT_FUSED_BAR_WORDS - 1, 0, sizeof(unsigned), c.st) != hipSuccess) {
       imt_set_error("decode_step: memset failed");   // a new search: clear the sticky status word
@@ -705,6 +706,8 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
     }
     return imt_decode_fused_launch(f, c.st);
   }
+  RC(imt_embed_ln_fwd(c.dtype, io->ids, io->pos_ids, io->type_ids, c.P(m->emb_word), c.P(m->emb_pos), c.P(m->emb_type), c.P(m->emb_ln_g),
+                      c.P(m->emb_ln_b), w.emb_sum, w.x, w.mean, w.rstd, R, 1, d, m->vocab, m->max_pos, m->n_types, m->ln_eps, 0.f, 0, c.st));
   const void* x = w.x;
   for (int l = 0; l < m->n_layers; ++l) {
     const imt_layer_desc& p = m->layers[l];

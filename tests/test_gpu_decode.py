@@ -371,7 +371,7 @@ def test_one_launch_decoder_step_matches_the_per_operator_chain(cuda, monkeypatc
     mask = torch.ones(B, Tk, dtype=torch.uint8)
     for b in range(B):
         mask[b, Tk - (b % 4):] = 0
-    mask = mask.cuda()
+    mask = None if Tk == 33 else mask.cuda()   # captioning decodes against image regions without a mask (image_model.py:311-377)
     T, rows_max = 6, B * beam
     store = store_of(ours.decoder).ensure()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

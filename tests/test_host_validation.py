@@ -126,6 +126,16 @@ def test_decode_descriptor_checks(lib):
     assert lib.imt_decode_step(ctypes.byref(dec), ctypes.byref(io), None, 0, None) == ERR and b"outside the cache" in lib.imt_last_error()
     io.pos = 3
     assert lib.imt_decode_step(ctypes.byref(dec), ctypes.byref(io), None, 0, None) == ERR and b"null tensor" in lib.imt_last_error()
+    # the one-launch step (bf16, hidden size 512) adds its per-layer hand-off buffers and barrier words to the workspace; a stack it does
+    # not cover has nothing to check
+    assert lib.imt_decode_check(ctypes.byref(dec), 0, 0x1000, None) == ERR and lib.imt_decode_check(ctypes.byref(dec), 8, None, None) == ERR
+    assert lib.imt_decode_check(ctypes.byref(enc), 8, 0x1000, None) == ERR and b"not a decoder" in lib.imt_last_error()
+    assert lib.imt_decode_check(ctypes.byref(dec), 8, 0x1000, None) == 0
+    small = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=2, d=512, heads=8, ff=2048, decoder=True, dtype=0)), 320)
+    fused = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=2, d=512, heads=8, ff=2048, decoder=True, dtype=1)), 320)
+    six = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=6, d=512, heads=8, ff=2048, decoder=True, dtype=1)), 320)
+    per_layer = 320 * (6 * 512 * 2 + 2048 * 2 + 3 * 512 * 4)
+    assert fused - small // 2 >= 2 * per_layer and six - fused == 4 * per_layer, (small, fused, six, per_layer)
 
 
 def test_row_kernel_argument_checks(lib):
