@@ -105,12 +105,23 @@ __global__ __launch_bounds__(FAST_THREADS) void beam_row_topk_fast_kernel(imt_be
   }
   const int V4 = a.V & ~3;
   // pass A: online max / sum-exp
+  // NS sweeps of the row are REQUESTED together before the first is consumed (clamped addresses, the value masked where used): one
+  // sweep per loop trip was a chain of ~8 exposed load latencies per pass -- 41 us per row where the row's 120 KB take ~1 us to stream
+  constexpr int NS = 4;
   float m = -INFINITY, l = 0.f;
-  for (int v = tid * 4; v < V4; v += FAST_THREADS * 4) {
-    const f32x4 q = *reinterpret_cast<const f32x4*>(x + v);
-    const float qm = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
-    if (qm > m) { l *= __expf(m - qm); m = qm; }
-    l += __expf(q[0] - m) + __expf(q[1] - m) + __expf(q[2] - m) + __expf(q[3] - m);
+  for (int v0 = tid * 4; v0 < V4; v0 += NS * FAST_THREADS * 4) {
+    f32x4 qs[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qs[s] = *reinterpret_cast<const f32x4*>(x + min(v0 + s * FAST_THREADS * 4, V4 - 4));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (v0 + s * FAST_THREADS * 4 < V4) {
+        const f32x4 q = qs[s];
+        const float qm = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3]));
+        if (qm > m) { l *= __expf(m - qm); m = qm; }
+        l += __expf(q[0] - m) + __expf(q[1] - m) + __expf(q[2] - m) + __expf(q[3] - m);
+      }
+    }
   }
   for (int v = V4 + tid; v < a.V; v += FAST_THREADS) {
     const float q = x[v];
@@ -149,29 +160,60 @@ __global__ __launch_bounds__(FAST_THREADS) void beam_row_topk_fast_kernel(imt_be
       if (!placed) { ls[0] = sc; li[0] = v; }
     }
   };
-  for (int v = tid * 4; v < V4; v += FAST_THREADS * 4) {
-    const f32x4 q = *reinterpret_cast<const f32x4*>(x + v);
+  for (int v0 = tid * 4; v0 < V4; v0 += NS * FAST_THREADS * 4) {
+    f32x4 qs[NS];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) offer(q[e], v + e);
+    for (int s = 0; s < NS; ++s) qs[s] = *reinterpret_cast<const f32x4*>(x + min(v0 + s * FAST_THREADS * 4, V4 - 4));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int v = v0 + s * FAST_THREADS * 4;
+      if (v < V4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) offer(qs[s][e], v + e);
+      }
+    }
   }
   for (int v = V4 + tid; v < a.V; v += FAST_THREADS) offer(x[v], v);
-  // K rounds over the threads' list heads
-  for (int t = 0; t < a.beam; ++t) {
-    float bs = ls[0]; int bi = li[0];
-    wave_best(bs, bi);
-    __syncthreads();
-    if (lane == 0) { red_f[wv] = bs; red_i[wv] = bi; }
-    __syncthreads();
-    bs = red_f[0]; bi = red_i[0];
+  // The row's K best in two stages without a block-wide round per pick (each cost ~2.4 us on 16 waves: two barriers and a scan of 16
+  // LDS slots): (1) every wave picks ITS K best from its lanes' list heads -- butterfly arg-best, the owning lane pops -- and parks them;
+  // (2) one barrier, then wave 0 holds one parked list per lane and picks the row's K best the same way.  Same order as before:
+  // (score desc, index asc) at every comparison, indices are unique.
+  __shared__ float wl_s[FAST_THREADS / 64][K];
+  __shared__ int wl_i[FAST_THREADS / 64][K];
 #pragma unroll
-    for (int k = 1; k < FAST_THREADS / 64; ++k)
-      if (better(red_f[k], red_i[k], bs, bi)) { bs = red_f[k]; bi = red_i[k]; }
-    if (li[0] == bi) {  // this thread owned the winner: pop it
+  for (int t = 0; t < K; ++t) {
+    if (t < a.beam) {
+      float bs = ls[0]; int bi = li[0];
+      wave_best(bs, bi);
+      if (li[0] == bi && bi != 0x7fffffff) {  // this lane owned the winner: pop it
 #pragma unroll
-      for (int k = 0; k < K - 1; ++k) { ls[k] = ls[k + 1]; li[k] = li[k + 1]; }
-      ls[K - 1] = -INFINITY; li[K - 1] = 0x7fffffff;
+        for (int k = 0; k < K - 1; ++k) { ls[k] = ls[k + 1]; li[k] = li[k + 1]; }
+        ls[K - 1] = -INFINITY; li[K - 1] = 0x7fffffff;
+      }
+      if (lane == 0) { wl_s[wv][t] = bs; wl_i[wv][t] = bi; }
     }
-    if (tid == 0) { cs[t] = bs; ci[t] = (bi == 0x7fffffff) ? t : bi; }  // (no finite score left, e.g. NaN logits: a valid index)
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const bool have = lane < FAST_THREADS / 64 && k < a.beam;
+      ls[k] = have ? wl_s[lane][k] : -INFINITY;
+      li[k] = have ? wl_i[lane][k] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      if (t < a.beam) {
+        float bs = ls[0]; int bi = li[0];
+        wave_best(bs, bi);
+        if (li[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+          for (int k = 0; k < K - 1; ++k) { ls[k] = ls[k + 1]; li[k] = li[k + 1]; }
+          ls[K - 1] = -INFINITY; li[K - 1] = 0x7fffffff;
+        }
+        if (lane == 0) { cs[t] = bs; ci[t] = (bi == 0x7fffffff) ? t : bi; }  // (no finite score left, e.g. NaN logits: a valid index)
+      }
+    }
   }
 }
 
