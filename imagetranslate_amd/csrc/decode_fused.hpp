@@ -3,7 +3,6 @@
 #include "common.hpp"
 
 constexpr int IMT_FUSED_MAX_LAYERS = 12;
-constexpr int IMT_FUSED_D = 512;            // hidden size the kernel is built for (BASELINE configs)
 constexpr int IMT_FUSED_BAR_WORDS = 32 * 20; // barrier counters (own 128-B lines) + status word
 
 struct ImtFusedLayer {
@@ -20,7 +19,7 @@ struct ImtFusedLayer {
 
 struct ImtFusedArgs {
   ImtFusedLayer L[IMT_FUSED_MAX_LAYERS];
-  int n_layers, R, rep, pos, Tk, t_max, r_max, H, dh, ff;
+  int n_layers, d, R, rep, pos, Tk, t_max, r_max, H, dh, ff;   // d: 512 or 768
   // BertEmbeddings of the newest tokens, computed while layer 0 stages its operand: word[ids] + pos[pos_ids] + type[type_ids] -> LayerNorm
   const int64_t *ids, *pos_ids, *type_ids;   // [R]; type_ids nullable (zeros)
   const bf16_t *emb_word, *emb_pos, *emb_type, *emb_g, *emb_b;
@@ -33,5 +32,6 @@ struct ImtFusedArgs {
 };
 
 int64_t imt_decode_fused_layer_bytes(int r_max, int d, int ff);   // hand-off buffers of one layer
+bool imt_decode_fused_shape(int d, int heads, int ff, int n_layers);   // bf16 stacks the one-launch step is built for
 bool imt_decode_fused_enabled();
 int imt_decode_fused_launch(const ImtFusedArgs& a, hipStream_t st);

@@ -566,9 +566,9 @@ struct DecodeWs {
   int64_t bytes;
 };
 
-// the one-launch decoder step is built for the BASELINE shape family: bf16, hidden size 512 in heads of 64, ff a multiple of 512
+// the one-launch decoder step (decode_fused.hip): bf16, hidden size 512 or 768 in heads of 64
 bool fused_decode_shape(const imt_stack_desc* m) {
-  return m->dtype == IMT_BF16 && m->d == IMT_FUSED_D && m->heads * 64 == m->d && m->ff % 512 == 0 && m->ff >= 512 && m->n_layers <= IMT_FUSED_MAX_LAYERS;
+  return m->dtype == IMT_BF16 && imt_decode_fused_shape(m->d, m->heads, m->ff, m->n_layers);
 }
 
 void carve_decode(const imt_stack_desc* m, int r_max, void* ws, DecodeWs& w) {
@@ -693,7 +693,7 @@ extern "C" int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io,
       L.h = (bf16_t*)fc.take(rm * ff * 2);
       L.pre1 = (float*)fc.take(rm * d * 4); L.pre2 = (float*)fc.take(rm * d * 4); L.pre3 = (float*)fc.take(rm * d * 4);
     }
-    f.n_layers = m->n_layers; f.R = R; f.rep = io->rep; f.pos = io->pos; f.Tk = io->Tk; f.t_max = io->t_max; f.r_max = io->r_max;
+    f.n_layers = m->n_layers; f.d = d; f.R = R; f.rep = io->rep; f.pos = io->pos; f.Tk = io->Tk; f.t_max = io->t_max; f.r_max = io->r_max;
     f.H = H; f.dh = dh; f.ff = ff;
     f.ids = io->ids; f.pos_ids = io->pos_ids; f.type_ids = io->type_ids;
     f.emb_word = P + m->emb_word; f.emb_pos = P + m->emb_pos; f.emb_type = P + m->emb_type; f.emb_g = P + m->emb_ln_g; f.emb_b = P + m->emb_ln_b;

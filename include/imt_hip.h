@@ -465,7 +465,7 @@ int64_t imt_decode_cross_bytes(const imt_stack_desc* m, int B, int Tk);
 /* cross K|V of every decoder layer from the encoder states [B,Tk,d] (one GEMM per layer). */
 int imt_decode_begin(const imt_stack_desc* m, const void* enc_states, int B, int Tk, void* cross_kv, void* stream);
 int imt_decode_step(const imt_stack_desc* m, const imt_decode_io* io, void* ws, int64_t ws_bytes, void* stream);
-/* bf16 stacks with hidden size 512 in heads of 64 run a step as ONE launch whose workgroups meet at grid-wide barriers with
+/* bf16 stacks with hidden size 512 or 768 in heads of 64 run a step as ONE launch whose workgroups meet at grid-wide barriers with
  * bounded waits (csrc/decode_fused.hip; IMT_DECODE_FUSED=0: the launch-per-operator chain).  A wait that runs out abandons
  * the launch and sets a status word in `ws` (cleared by the step with pos == 0).  imt_decode_check synchronises `stream`
  * and returns IMT_ERR_LAUNCH if any step since then was abandoned, IMT_OK otherwise (and always for other stacks):

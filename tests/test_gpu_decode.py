@@ -347,9 +347,10 @@ def test_beam_first_step_against_reference_beam_decoder(cuda, name, kv_cache):
     check_beam_step1(case, toks, padded, None, inp["first_tokens"])
 
 
-@pytest.mark.parametrize("layers,B,beam,Tk", [(2, 7, 5, 40), (6, 64, 5, 128), (2, 3, 1, 9), (2, 5, 3, 21), (1, 9, 4, 150), (2, 4, 2, 64), (1, 6, 7, 33)])
-def test_one_launch_decoder_step_matches_the_per_operator_chain(cuda, monkeypatch, layers, B, beam, Tk):
-    """csrc/decode_fused.hip (bf16, hidden size 512: ONE launch per decoding step, grid-wide barriers between its phases)
+@pytest.mark.parametrize("layers,B,beam,Tk,d", [(2, 7, 5, 40, 512), (6, 64, 5, 128, 512), (2, 3, 1, 9, 512), (2, 5, 3, 21, 512), (1, 9, 4, 150, 512),
+                                               (2, 4, 2, 64, 512), (1, 6, 7, 33, 512), (2, 7, 5, 40, 768), (3, 64, 5, 100, 768), (1, 3, 1, 33, 768)])
+def test_one_launch_decoder_step_matches_the_per_operator_chain(cuda, monkeypatch, layers, B, beam, Tk, d):
+    """csrc/decode_fused.hip (bf16, hidden size 512 or 768 -- the reference's default --embed --: ONE launch per decoding step, grid-wide barriers between its phases)
     against the launch-per-operator chain of imt_decode_step on the same weights, tokens, slot tables and caches: hidden
     states of every step and the q|k|v written into the cache.  Both compute in bf16 with fp32 accumulation; they differ in
     where a pre-LayerNorm sum is rounded, hence the tolerance.  Row counts that are not multiples of the 32-row items, a
@@ -360,14 +361,14 @@ def test_one_launch_decoder_step_matches_the_per_operator_chain(cuda, monkeypatc
     from imagetranslate_amd.seq_gen import _Incremental
     torch.manual_seed(5)
     tp = R.SyntheticTextProcessor(1000)
-    ours = S.Seq2Seq(tp, lang_dec=False, enc_layer=1, dec_layer=layers, embed_dim=512, intermediate_dim=2048, num_attention_heads=8)
+    ours = S.Seq2Seq(tp, lang_dec=False, enc_layer=1, dec_layer=layers, embed_dim=d, intermediate_dim=4 * d, num_attention_heads=d // 64)
     for p in ours.parameters():   # biases and LayerNorm parameters away from their (0, 1) initial values
         if p.dim() == 1:
             p.data.add_(0.1 * torch.randn_like(p))
     ours = ours.cuda().eval()
     ours.set_compute_dtype(torch.bfloat16)
     g = torch.Generator().manual_seed(1)
-    enc = torch.randn(B, Tk, 512, generator=g).cuda().bfloat16().contiguous()
+    enc = torch.randn(B, Tk, d, generator=g).cuda().bfloat16().contiguous()
     mask = torch.ones(B, Tk, dtype=torch.uint8)
     for b in range(B):
         mask[b, Tk - (b % 4):] = 0
@@ -400,7 +401,7 @@ def test_one_launch_decoder_step_matches_the_per_operator_chain(cuda, monkeypatc
         for t in range(T):
             rep = 1 if t == 0 else beam
             rows = B * rep
-            out = torch.zeros(rows_max, 512, device="cuda", dtype=dt)
+            out = torch.zeros(rows_max, d, device="cuda", dtype=dt)
             inc.step(t, rows, rep, toks[t, :rows].contiguous(), types[:rows].contiguous(), slot_tabs[t], out)
             outs.append(out[:rows].float().clone())
         inc.check()

@@ -136,6 +136,12 @@ def test_decode_descriptor_checks(lib):
     six = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=6, d=512, heads=8, ff=2048, decoder=True, dtype=1)), 320)
     per_layer = 320 * (6 * 512 * 2 + 2048 * 2 + 3 * 512 * 4)
     assert fused - small // 2 >= 2 * per_layer and six - fused == 4 * per_layer, (small, fused, six, per_layer)
+    ref = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=3, d=768, heads=12, ff=3072, decoder=True, dtype=1)), 320)
+    ref1 = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=2, d=768, heads=12, ff=3072, decoder=True, dtype=1)), 320)
+    assert ref - ref1 == 320 * (6 * 768 * 2 + 3072 * 2 + 3 * 768 * 4)   # the reference's default shape takes the one-launch step too
+    odd = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=3, d=1024, heads=16, ff=4096, decoder=True, dtype=1)), 320)
+    odd1 = lib.imt_decode_workspace_bytes(ctypes.byref(_stack(n_layers=2, d=1024, heads=16, ff=4096, decoder=True, dtype=1)), 320)
+    assert odd == odd1                                                   # other shapes: the chain, no per-layer buffers
 
 
 def test_row_kernel_argument_checks(lib):

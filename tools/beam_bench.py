@@ -15,7 +15,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     beam = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    cfg = CONFIGS["c1"]
+    cfg = CONFIGS[os.environ.get("BEAM_BENCH_CONFIG", "c1")]   # e.g. ref768: the reference's default --embed 768 / 12 heads / 3072
     model = build_model(cfg, torch.bfloat16, torch.device("cuda")).eval()
     g = torch.Generator().manual_seed(1234)
     src = torch.randint(6, cfg["V"], (B, S), generator=g)
