@@ -296,6 +296,34 @@ def test_beam_decoder_bf16_and_list_wrapped_args(cuda):
         assert int(o[0]) == 5 and (o != 4).all()
 
 
+@pytest.mark.parametrize("beam", [1, 5])
+def test_beam_search_with_the_one_launch_step(cuda, monkeypatch, beam):
+    """A whole BeamDecoder search at the size where the one-launch decoder step applies (bf16, hidden size 512): the tokens of its first
+    steps agree with the launch-per-operator chain on (nearly) every sentence -- later positions may part where bf16 rounding flips a
+    near-tie of these random weights -- every output row is well-formed, and the end-of-search imt_decode_check raises nothing."""
+    import imagetranslate_amd.seq2seq as S
+    from imagetranslate_amd.seq_gen import BeamDecoder
+    torch.manual_seed(11)
+    tp = R.SyntheticTextProcessor(1000)
+    ours = S.Seq2Seq(tp, lang_dec=False, enc_layer=2, dec_layer=3, embed_dim=512, intermediate_dim=2048, num_attention_heads=8).cuda().eval()
+    ours.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    B, Sx = 12, 24
+    src = torch.randint(6, 1000, (B, Sx), generator=g)
+    src[:, 0], src[:, -1] = 5, 4
+    mask = torch.ones(B, Sx, dtype=torch.bool)
+    args = dict(src_inputs=src.cuda(), src_sizes=torch.full((B,), Sx), first_tokens=torch.full((B,), 5), src_mask=mask.cuda(),
+                src_langs=torch.zeros(B, dtype=torch.long).cuda(), tgt_langs=torch.ones(B, dtype=torch.long).cuda(), pad_idx=0)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("IMT_DECODE_FUSED", fused)
+        outs[fused] = BeamDecoder(ours, beam_width=beam, kv_cache=True)(max_len=12, **args)
+    head = sum(int(x[:4].tolist() == y[:4].tolist()) for x, y in zip(outs["1"], outs["0"]))
+    assert head >= B - 2, "the first tokens of %d of %d sentences differ between the one-launch step and the chain" % (B - head, B)
+    for o in outs["1"]:
+        assert int(o[0]) == 5 and 2 <= len(o) <= 12 and bool(((o >= 0) & (o < 1000)).all())
+
+
 def test_decode_step_matches_full_decoder(cuda):
     """imt_decode_step hidden states == last row of the full decoder forward on the same prefix (fp32)."""
     from imagetranslate_amd import _lib as L
