@@ -68,10 +68,10 @@ IMT_DEVICE void attn_decode_wave(const imt_attn_decode_args& a, int w) {
   float m = -INFINITY, l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // UNR key groups per iteration: their slot lookups, then their K/V row segments, are all in flight before the first
   // dependent softmax update (one group per iteration was a chain of exposed load latencies: 18.7 us at 145 keys)
-  // bf16 rows wait in registers as loaded (16 bytes = 4 registers each), so twice as many groups fit: 64 keys of a 64-wide head per
-  // iteration, i.e. at most three dependent round trips for the longest sentences.  (The groups are consumed in the same order
-  // whatever UNR is: results do not depend on it.)
-  constexpr int UNR = UNR_ ? UNR_ : (sizeof(T) == 2 ? 8 : 4);   // (UNR_: the one-launch step runs 16 waves per CU on 128 registers)
+  // bf16 rows wait in registers as loaded (16 bytes = 4 registers each), so more groups fit: six = 48 keys of a 64-wide head per
+  // iteration at 124 registers (four waves per SIMD; eight groups take 134 and drop to three).  (The groups are consumed in the same
+  // order whatever UNR is: results do not depend on it.)
+  constexpr int UNR = UNR_ ? UNR_ : (sizeof(T) == 2 ? 6 : 4);   // (UNR_: the one-launch step runs 16 waves per CU on 128 registers)
   for (int j0 = 0; j0 < a.n_keys; j0 += G * UNR) {
     typename Raw8<T>::type k[UNR], v[UNR];
     int jj[UNR];
